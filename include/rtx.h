@@ -1,0 +1,221 @@
+/*
+ * rtx.h — C ABI of the MI355X path-trace library (librtx.so).
+ *
+ * The reference tracer has no plugin / FFI boundary: main() calls
+ * Scene::render() directly (Raytrace_C++/Src/main.cpp:11-12) and render() runs
+ * the pixel / sample / path loops on the host (Scene.cpp:134-156).  This header
+ * is the boundary placed where Scene::render() hands off to per-pixel work
+ * (Scene.cpp:137-153): the host scene API flattens world / light / camera into
+ * the plain arrays of RtxScene and the library renders them on the GPU.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every buffer; the
+ * library copies what it needs during the call and never keeps a host pointer;
+ * every entry point returns 0 on success or a negative RtxStatus and never
+ * throws; rtx_last_error() describes the last failure on the calling thread.
+ * One context drives one GPU; a context must not be used from two threads at
+ * once, different contexts may be.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_ABI_VERSION 1u
+
+typedef enum RtxStatus {
+    RTX_OK = 0,
+    RTX_ERR_INVALID_ARGUMENT = -1,
+    RTX_ERR_NO_DEVICE = -2,
+    RTX_ERR_HIP = -3,
+    RTX_ERR_NO_SCENE = -4,
+    RTX_ERR_UNSUPPORTED = -5,
+    RTX_ERR_TOO_LARGE = -6
+} RtxStatus;
+
+/* Primitive kinds (Rect::AxisType, Rect.h:7-11, plus Sphere). */
+enum { RTX_PRIM_RECT_XY = 0, RTX_PRIM_RECT_XZ = 1, RTX_PRIM_RECT_YZ = 2, RTX_PRIM_SPHERE = 3 };
+/* Light-list entry kinds; OTHER = any shape that keeps Shape's default
+ * pdf_value()/random() (Shape.h:8-9: 0 and (1,0,0)). */
+enum { RTX_LIGHT_RECT_XY = 0, RTX_LIGHT_RECT_XZ = 1, RTX_LIGHT_RECT_YZ = 2, RTX_LIGHT_SPHERE = 3, RTX_LIGHT_OTHER = 4 };
+/* Transform steps (Translate.h:7, Rotate.h:7). */
+enum { RTX_STEP_TRANSLATE = 0, RTX_STEP_ROTATE = 1 };
+/* Material kinds (Lambertian.h, Metal.h, Dielectric.h, DiffuseLight.h). */
+enum { RTX_MAT_LAMBERTIAN = 0, RTX_MAT_METAL = 1, RTX_MAT_DIELECTRIC = 2, RTX_MAT_DIFFUSE_LIGHT = 3 };
+/* Texture kinds (ColorTexture.h, CheckerTexture.h). */
+enum { RTX_TEX_COLOR = 0, RTX_TEX_CHECKER = 1 };
+/* Acceleration structure choice for rtx_upload_scene(). */
+enum { RTX_ACCEL_AUTO = 0, RTX_ACCEL_LINEAR = 1, RTX_ACCEL_BVH = 2 };
+/* Arithmetic modes of a render. */
+enum {
+    RTX_MODE_FAST = 0,          /* fused multiply-add, reciprocal-based division, native sin/cos */
+    RTX_MODE_DETERMINISTIC = 1  /* the reference's exact fp32 operation order; path geometry is
+                                   bit-identical to the reference tracer fed the same stream */
+};
+
+/*
+ * A flattened scene: struct of arrays, host memory, read-only during the call.
+ *
+ * Primitives are the leaves (Rect / Sphere) of the world shape in depth-first
+ * order, which is the order ShapeList::hit (ShapeList.cpp:5-17) visits them;
+ * Box (Box.cpp:11-29) contributes its six rects.  FlipNormals wrappers collapse
+ * to a parity bit; Translate / Rotate wrappers become an ordered chain of steps
+ * (outermost first) shared by every leaf below them.
+ */
+typedef struct RtxScene {
+    uint32_t abi_version; /* RTX_ABI_VERSION */
+
+    /* world primitives */
+    uint32_t n_prims;
+    const uint32_t* prim_kind;     /* RTX_PRIM_* */
+    const uint32_t* prim_flip;     /* 1 = normal negated (FlipNormals.cpp:8) */
+    const uint32_t* prim_material; /* index into mat_* */
+    const uint32_t* prim_chain;    /* index into chain_begin; chain 0 is the empty chain */
+    const float* prim_a;           /* rect x0 (Rect.h:30) | sphere centre x */
+    const float* prim_b;           /* rect x1             | sphere centre y */
+    const float* prim_c;           /* rect y0             | sphere centre z */
+    const float* prim_d;           /* rect y1             | sphere radius   */
+    const float* prim_e;           /* rect k              | unused          */
+
+    /* transform chains: steps chain_begin[c] .. chain_begin[c+1]-1, outermost wrapper first */
+    uint32_t n_chains;             /* >= 1; chain 0 has no steps */
+    const uint32_t* chain_begin;   /* n_chains + 1 entries */
+    uint32_t n_steps;
+    const uint32_t* step_kind;     /* RTX_STEP_* */
+    const float* step_x;           /* translate: offset xyz, w unused (Translate.cpp:7-9)      */
+    const float* step_y;           /* rotate: unit quaternion xyzw (Rotate.h:9, quat_aos.h:348) */
+    const float* step_z;
+    const float* step_w;
+
+    /* materials */
+    uint32_t n_materials;
+    const uint32_t* mat_kind;      /* RTX_MAT_* */
+    const uint32_t* mat_texture;   /* albedo / emission texture; unused for dielectrics */
+    const float* mat_param;        /* Metal: fuzz (Metal.h:23); Dielectric: ri (Dielectric.h:14) */
+
+    /* textures */
+    uint32_t n_textures;
+    const uint32_t* tex_kind;      /* RTX_TEX_* */
+    const float* tex_r;            /* colour: rgb (ColorTexture.h:15)                     */
+    const float* tex_g;            /* checker: tex_r = frequency (CheckerTexture.h:18)    */
+    const float* tex_b;
+    const uint32_t* tex_odd;       /* checker: sub-texture when the sine product is < 0  */
+    const uint32_t* tex_even;      /* checker: sub-texture otherwise (CheckerTexture.cpp:5-10) */
+
+    /* light shape handed to Scene::color (Scene.cpp:113) */
+    uint32_t n_lights;             /* >= 1 */
+    uint32_t light_is_list;        /* 1: a ShapeList (one extra draw picks the entry,
+                                      ShapeList.cpp:28-35); 0: a single bare shape */
+    const uint32_t* light_kind;    /* RTX_LIGHT_* */
+    const float* light_a;          /* same meaning as prim_a..prim_e */
+    const float* light_b;
+    const float* light_c;
+    const float* light_d;
+    const float* light_e;
+
+    /* pinhole camera (Camera.h:19-26): ray = origin, ll + u*s + v*t - origin */
+    float cam_origin[3];
+    float cam_ll[3];
+    float cam_u[3];
+    float cam_v[3];
+
+    float background[3];           /* Scene::background (Scene.h:20-22) */
+} RtxScene;
+
+typedef struct RtxParams {
+    uint32_t width;
+    uint32_t height;
+    uint32_t spp_begin;   /* absolute index of the first sample rendered by this call */
+    uint32_t spp_count;   /* samples per pixel rendered by this call */
+    uint32_t max_depth;   /* MAX_DEPTH (Scene.cpp:9): scatter is skipped at this depth; 50 */
+    uint32_t mode;        /* RTX_MODE_* */
+    uint64_t seed;
+    uint32_t accumulate;  /* 0: overwrite the accumulator; 1: add to it */
+    uint32_t reserved;
+} RtxParams;
+
+/* One nearest-hit record of rtx_hit(), the image of the reference's HitRec (HitRec.h:3-10). */
+typedef struct RtxHit {
+    int32_t hit;          /* 1 / 0 */
+    int32_t prim;         /* index of the winning primitive, -1 on a miss */
+    float t;
+    float p[3];
+    float n[3];
+    int32_t material;     /* material index, -1 on a miss */
+} RtxHit;
+
+typedef struct RtxContext RtxContext;
+
+/* Library / device bring-up.  `device` is a HIP device ordinal. */
+int rtx_create(int device, RtxContext** out_ctx);
+void rtx_destroy(RtxContext* ctx);
+const char* rtx_last_error(void);
+/* 1 if a HIP device is usable from this process, 0 otherwise (never fails). */
+int rtx_device_count(void);
+
+/* Copy the scene to the GPU (and build the BVH when asked or when AUTO decides). */
+int rtx_upload_scene(RtxContext* ctx, const RtxScene* scene, uint32_t accel);
+
+/*
+ * Render samples [spp_begin, spp_begin+spp_count) of every pixel: the device
+ * counterpart of the loops of Scene::render (Scene.cpp:140-149) around
+ * Scene::color (Scene.cpp:103-132).
+ *   accum_rgb   HOST buffer, width*height*3 fp32, row 0 = top image row (the
+ *               reference writes pixel (i,j) to row ny-j-1, Scene.cpp:151); receives
+ *               the SUM of the samples' radiance (divide by the sample count to get
+ *               the reference's `c /= ns`).
+ *   rays_out    optional: nearest-hit queries issued (one per path segment).
+ */
+int rtx_render(RtxContext* ctx, const RtxParams* params, float* accum_rgb, uint64_t* rays_out);
+
+/*
+ * Same, but the accumulator and the ray counter are DEVICE buffers on the
+ * context's GPU and the work is enqueued on `hip_stream` (a hipStream_t, NULL =
+ * the default stream) without waiting for it.  `d_rays` (optional, 8 bytes) is
+ * incremented, not overwritten.
+ */
+int rtx_render_device(RtxContext* ctx, const RtxParams* params, float* d_accum_rgb,
+                      unsigned long long* d_rays, void* hip_stream);
+
+/*
+ * Deterministic-mode debugging aid: per-sample radiance and segment counts.
+ *   sample_rgb       HOST, [height*width][spp_count][3], pixel index j*width+i with j
+ *                    counted from the BOTTOM row (the reference's loop variables).
+ *   sample_segments  HOST, optional, [height*width][spp_count].
+ */
+int rtx_render_samples(RtxContext* ctx, const RtxParams* params, float* sample_rgb,
+                       uint32_t* sample_segments);
+
+/*
+ * Nearest hit of n arbitrary rays in (t0, t1): Shape::hit of the world
+ * (Shape.h:7, ShapeList.cpp:5-17).  `origins` / `directions` are HOST arrays of
+ * 3n floats; `hits` is a HOST array of n records.  mode as in RtxParams.
+ */
+int rtx_hit(RtxContext* ctx, uint32_t n, const float* origins, const float* directions, float t0,
+            float t1, uint32_t mode, RtxHit* hits);
+
+/*
+ * The reference's per-pixel epilogue (Scene.cpp:150-151, Image.h:30-39):
+ * sum / ns, NaN filter, gamma 1/2.2, clamp, *255.99 truncated.  `d_accum_rgb` is a
+ * DEVICE accumulator, `rgb8` a HOST buffer of width*height*3 bytes, row 0 = top.
+ */
+int rtx_resolve_device(RtxContext* ctx, uint32_t width, uint32_t height, uint32_t ns,
+                       const float* d_accum_rgb, uint8_t* rgb8, void* hip_stream);
+
+/* Introspection for tests and reports. */
+typedef struct RtxSceneInfo {
+    uint32_t n_prims;
+    uint32_t n_items;      /* top-level BVH items (single primitives or whole transformed instances) */
+    uint32_t n_bvh_nodes;  /* 0 when the linear scan is used */
+    uint32_t accel;        /* RTX_ACCEL_LINEAR or RTX_ACCEL_BVH actually in use */
+} RtxSceneInfo;
+int rtx_scene_info(RtxContext* ctx, RtxSceneInfo* out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RTX_H */

@@ -1,0 +1,254 @@
+/*
+ * ref_driver.cpp — C interface around the UNMODIFIED reference tracer, built
+ * into oracle/_ref/libref_oracle.so by oracle/Makefile together with the
+ * reference's own translation units (compiled in place from /root/reference).
+ *
+ * TEST INFRASTRUCTURE ONLY: used by tests/, by __graft_entry__.smoke() and by
+ * the cpu_baseline leg of bench.py as the checker / the reported CPU baseline.
+ * The renderer never loads this library.
+ *
+ * What it drives is the reference's public integrator
+ *   Vector3 Scene::color(const Ray&, const Shape* world, const Shape* light, int depth)
+ * (Raytrace_C++/Src/Scene.cpp:103-132) with the pixel / sample loop of
+ * Scene::render() (Scene.cpp:140-151) restated here because the reference's
+ * own loop writes straight into an 8-bit image and cannot expose per-sample
+ * radiance.  The random stream is the counter-based one of include/rtx_det.h,
+ * substituted for rand() by oracle/ref_shim.h.
+ */
+#define private public /* reach Scene::m_world / m_light / m_camera / m_backColor (Scene.h:37-43) */
+#include "Scene.h"
+#undef private
+
+#include "ShapeList.h"
+#include "ShapeBuilder.h"
+#include "HitRec.h"
+#include "ScatterRec.h"
+#include "Lambertian.h"
+#include "Metal.h"
+#include "Dielectric.h"
+#include "DiffuseLight.h"
+#include "ColorTexture.h"
+#include "CheckerTexture.h"
+#include <stb_image_write.h> /* declarations only; the implementation is compiled in Scene.cpp:3-6 */
+
+// internal linkage: the renderer's host library includes the same file against its own classes
+namespace {
+#include "../raytrace_amd/host/scenes.inc"
+}  // namespace
+
+thread_local RtxRng g_rt_rng = {0u, 1u};
+thread_local unsigned long long g_rt_draws = 0;
+static thread_local unsigned long long tl_segments = 0;
+
+namespace {
+
+// Counts nearest-hit queries issued by Scene::color (one per path segment).
+class CountingWorld : public Shape {
+public:
+    explicit CountingWorld(const Shape* inner) : m_inner(inner) {}
+    bool hit(const Ray& r, float t0, float t1, HitRec& hrec) const override {
+        ++tl_segments;
+        return m_inner->hit(r, t0, t1, hrec);
+    }
+
+private:
+    const Shape* m_inner;
+};
+
+struct RefScene {
+    std::unique_ptr<Scene> scene;  // supplies color() and the background
+    const Shape* world = nullptr;
+    const Shape* light = nullptr;
+    const Camera* camera = nullptr;
+    std::unique_ptr<Camera> own_camera;
+    std::unique_ptr<ShapeList> own_world, own_light;
+    std::unique_ptr<CountingWorld> counted;
+    int w = 0, h = 0;
+};
+
+int material_kind(const MaterialPtr& m) {
+    if (!m) return -1;
+    if (dynamic_cast<Lambertian*>(m.get())) return 0;
+    if (dynamic_cast<Metal*>(m.get())) return 1;
+    if (dynamic_cast<Dielectric*>(m.get())) return 2;
+    if (dynamic_cast<DiffuseLight*>(m.get())) return 3;
+    return 4;
+}
+
+}  // namespace
+
+extern "C" {
+
+/*
+ * name == "cornell_builtin": world / light / camera come from the reference's own
+ * Scene::build().  Any other name: built by scenes.inc through the reference's
+ * ShapeBuilder API.
+ */
+void* ref_scene_create(const char* name, int w, int h) {
+    auto rs = std::make_unique<RefScene>();
+    rs->w = w;
+    rs->h = h;
+    rs->scene = std::make_unique<Scene>("unused.bmp", w, h, 1);
+    if (std::string(name) == "cornell_builtin") {
+        rs->scene->build();
+        rs->world = rs->scene->m_world.get();
+        rs->light = rs->scene->m_light.get();
+        rs->camera = rs->scene->m_camera.get();
+    } else {
+        SceneParts parts;
+        if (!make_scene(name, w, h, parts)) return nullptr;
+        rs->own_camera.reset(parts.camera);
+        rs->own_world.reset(parts.world);
+        rs->own_light.reset(parts.light);
+        rs->scene->m_backColor = parts.background;
+        rs->world = rs->own_world.get();
+        rs->light = rs->own_light.get();
+        rs->camera = rs->own_camera.get();
+    }
+    rs->counted = std::make_unique<CountingWorld>(rs->world);
+    return rs.release();
+}
+
+void ref_scene_destroy(void* p) { delete static_cast<RefScene*>(p); }
+
+/*
+ * Radiance of samples [spp_begin, spp_begin+spp_count) of every pixel.
+ *   sum_rgb            [h][w][3], row 0 = TOP image row (the reference stores pixel
+ *                      (i, j) at row ny-j-1, Scene.cpp:151); fp32 running sum in
+ *                      sample order, i.e. the reference's `c` before `c /= ns`.
+ *   per_sample_rgb     optional [h*w][spp_count][3], pixel index = j*w+i, j from the
+ *                      bottom (the reference's loop variables).
+ *   per_sample_segments optional [h*w][spp_count]: world->hit calls of that sample.
+ */
+int ref_render(void* p, int spp_begin, int spp_count, uint64_t seed, int n_threads,
+               float* sum_rgb, float* per_sample_rgb, uint32_t* per_sample_segments,
+               uint64_t* total_rays, uint64_t* total_draws) {
+    RefScene* rs = static_cast<RefScene*>(p);
+    if (!rs || spp_count < 0) return -1;
+    const int nx = rs->w, ny = rs->h;
+    std::atomic<int> next_row(0);
+    std::atomic<unsigned long long> rays(0), draws(0);
+    auto worker = [&]() {
+        unsigned long long my_rays = 0, my_draws = 0;
+        for (;;) {
+            int j = next_row.fetch_add(1);
+            if (j >= ny) break;
+            for (int i = 0; i < nx; ++i) {
+                Vector3 c(0);
+                const uint32_t pixel = uint32_t(j) * uint32_t(nx) + uint32_t(i);
+                for (int s = 0; s < spp_count; ++s) {
+                    rtx_rng_init(&g_rt_rng, pixel, uint32_t(spp_begin + s), seed);
+                    g_rt_draws = 0;
+                    tl_segments = 0;
+                    float u = (float(i) + rt_reference_drand48()) / float(nx);
+                    float v = (float(j) + rt_reference_drand48()) / float(ny);
+                    Ray r = rs->camera->getRay(u, v);
+                    Vector3 L = rs->scene->color(r, rs->counted.get(), rs->light, 0);
+                    c += L;
+                    my_rays += tl_segments;
+                    my_draws += g_rt_draws;
+                    if (per_sample_rgb) {
+                        float* o = per_sample_rgb + (size_t(pixel) * spp_count + s) * 3;
+                        o[0] = L.getX();
+                        o[1] = L.getY();
+                        o[2] = L.getZ();
+                    }
+                    if (per_sample_segments)
+                        per_sample_segments[size_t(pixel) * spp_count + s] = uint32_t(tl_segments);
+                }
+                if (sum_rgb) {
+                    float* o = sum_rgb + (size_t(ny - j - 1) * nx + i) * 3;
+                    o[0] = c.getX();
+                    o[1] = c.getY();
+                    o[2] = c.getZ();
+                }
+            }
+        }
+        rays += my_rays;
+        draws += my_draws;
+    };
+    if (n_threads <= 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(worker);
+        for (auto& t : pool) t.join();
+    }
+    if (total_rays) *total_rays = rays.load();
+    if (total_draws) *total_draws = draws.load();
+    return 0;
+}
+
+/* Nearest hit of n arbitrary rays against the scene's world (Shape::hit, Shape.h:7). */
+int ref_hit(void* p, int n, const float* org, const float* dir, float t0, float t1, int32_t* hit,
+            float* t, float* pos, float* nrm, float* uv, int32_t* mat_kind) {
+    RefScene* rs = static_cast<RefScene*>(p);
+    if (!rs) return -1;
+    for (int k = 0; k < n; ++k) {
+        Ray r(Vector3(org[3 * k], org[3 * k + 1], org[3 * k + 2]),
+              Vector3(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]));
+        HitRec hrec;
+        bool h = rs->world->hit(r, t0, t1, hrec);
+        hit[k] = h ? 1 : 0;
+        if (h) {
+            t[k] = hrec.t;
+            for (int c = 0; c < 3; ++c) {
+                pos[3 * k + c] = hrec.p[c];
+                nrm[3 * k + c] = hrec.n[c];
+            }
+            uv[2 * k] = hrec.u;
+            uv[2 * k + 1] = hrec.v;
+            mat_kind[k] = material_kind(hrec.mat);
+        } else {
+            t[k] = 0.0f;
+            for (int c = 0; c < 3; ++c) pos[3 * k + c] = nrm[3 * k + c] = 0.0f;
+            uv[2 * k] = uv[2 * k + 1] = 0.0f;
+            mat_kind[k] = -1;
+        }
+    }
+    return 0;
+}
+
+/* Camera::getRay (Camera.h:24-26) for n (u,v) pairs. */
+int ref_camera_rays(void* p, int n, const float* uv, float* org, float* dir) {
+    RefScene* rs = static_cast<RefScene*>(p);
+    if (!rs) return -1;
+    for (int k = 0; k < n; ++k) {
+        Ray r = rs->camera->getRay(uv[2 * k], uv[2 * k + 1]);
+        for (int c = 0; c < 3; ++c) {
+            org[3 * k + c] = r.origin()[c];
+            dir[3 * k + c] = r.direction()[c];
+        }
+    }
+    return 0;
+}
+
+/* Image::write (Image.h:30-39): NaN filter, gamma, clamp, 8-bit quantisation. */
+void ref_image_write(int n, const float* rgb, uint8_t* out) {
+    Image img(n, 1);
+    for (int k = 0; k < n; ++k) img.write(k, 0, rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2]);
+    memcpy(out, img.pixels(), size_t(n) * 3);
+}
+
+/*
+ * The reference's per-pixel epilogue (Scene.cpp:150-151): c /= ns, Image::write at
+ * row ny-j-1.  `sum_rgb` is laid out as ref_render() returns it (row 0 = top).
+ */
+void ref_resolve(int w, int h, int ns, const float* sum_rgb, uint8_t* out) {
+    Image img(w, h);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const float* s = sum_rgb + (size_t(y) * w + x) * 3;
+            Vector3 c(s[0], s[1], s[2]);
+            c /= ns;
+            img.write(x, y, c.getX(), c.getY(), c.getZ());
+        }
+    memcpy(out, img.pixels(), size_t(w) * h * 3);
+}
+
+/* The whole reference pipeline including its BMP writer (Scene.cpp:155). */
+int ref_write_bmp(const char* path, int w, int h, const uint8_t* rgb) {
+    return stbi_write_bmp(path, w, h, 3, rgb);
+}
+
+}  // extern "C"

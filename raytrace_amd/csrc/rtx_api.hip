@@ -1,0 +1,425 @@
+// rtx_api.hip — the C ABI of include/rtx.h: context, scene upload (repacking the
+// caller's struct-of-arrays into the 32-byte device records of rtx_device.h and
+// building the BVH), and the render / hit / resolve entry points.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rtx.h"
+#include "rtx_bvh.h"
+#include "rtx_device.h"
+#include "rtx_launch.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& what) {
+    g_last_error = what;
+    return code;
+}
+
+#define RTX_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(RTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+template <typename T>
+struct DeviceArray {
+    T* ptr = nullptr;
+    size_t count = 0;
+    ~DeviceArray() { release(); }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+    hipError_t resize(size_t n) {
+        if (n <= count && ptr) return hipSuccess;
+        release();
+        if (n == 0) return hipSuccess;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
+        if (e == hipSuccess) count = n;
+        return e;
+    }
+    hipError_t upload(const std::vector<T>& host) {
+        hipError_t e = resize(std::max<size_t>(host.size(), 1));
+        if (e != hipSuccess || host.empty()) return e;
+        return hipMemcpy(ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+}  // namespace
+
+struct RtxContext {
+    int device = 0;
+    bool has_scene = false;
+    rtxd::SceneView view{};
+    RtxSceneInfo info{};
+    DeviceArray<rtxd::Prim> prims;
+    DeviceArray<rtxd::Group> groups;
+    DeviceArray<rtxd::Step> steps;
+    DeviceArray<rtxd::Material> materials;
+    DeviceArray<rtxd::Texture> textures;
+    DeviceArray<rtxd::Light> lights;
+    DeviceArray<rtxd::BvhNode> bvh;
+    DeviceArray<uint32_t> bvh_items;
+    // scratch owned by the host-buffer entry points
+    DeviceArray<float> accum;
+    DeviceArray<unsigned long long> rays;
+    DeviceArray<float> sample_rgb;
+    DeviceArray<uint32_t> sample_segments;
+    DeviceArray<float> ray_o, ray_d;
+    DeviceArray<RtxHit> hits;
+    DeviceArray<uint8_t> rgb8;
+};
+
+namespace {
+
+int check_scene(const RtxScene* s) {
+    if (!s) return fail(RTX_ERR_INVALID_ARGUMENT, "scene is null");
+    if (s->abi_version != RTX_ABI_VERSION)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "RtxScene.abi_version does not match this library");
+    if (s->n_prims == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "scene has no primitives");
+    if (s->n_lights == 0)
+        return fail(RTX_ERR_INVALID_ARGUMENT,
+                    "light list is empty (the reference indexes m_list[0] of an empty list, "
+                    "ShapeList.cpp:28-35)");
+    if (s->n_chains == 0 || !s->chain_begin)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "chain table missing (chain 0 must exist and be empty)");
+    if (s->chain_begin[0] != 0 || s->chain_begin[1] != 0)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "chain 0 must be the empty chain");
+    if (s->chain_begin[s->n_chains] != s->n_steps)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "chain_begin[n_chains] != n_steps");
+    for (uint32_t c = 0; c < s->n_chains; ++c)
+        if (s->chain_begin[c] > s->chain_begin[c + 1])
+            return fail(RTX_ERR_INVALID_ARGUMENT, "chain_begin is not monotone");
+    if (!s->prim_kind || !s->prim_flip || !s->prim_material || !s->prim_chain || !s->prim_a ||
+        !s->prim_b || !s->prim_c || !s->prim_d || !s->prim_e)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "a primitive array is null");
+    if (s->n_steps && (!s->step_kind || !s->step_x || !s->step_y || !s->step_z || !s->step_w))
+        return fail(RTX_ERR_INVALID_ARGUMENT, "a step array is null");
+    if (s->n_materials == 0 || !s->mat_kind || !s->mat_texture || !s->mat_param)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "material table missing");
+    if (s->n_textures && (!s->tex_kind || !s->tex_r || !s->tex_g || !s->tex_b || !s->tex_odd || !s->tex_even))
+        return fail(RTX_ERR_INVALID_ARGUMENT, "a texture array is null");
+    if (!s->light_kind || !s->light_a || !s->light_b || !s->light_c || !s->light_d || !s->light_e)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "a light array is null");
+    for (uint32_t p = 0; p < s->n_prims; ++p) {
+        if (s->prim_kind[p] > RTX_PRIM_SPHERE) return fail(RTX_ERR_INVALID_ARGUMENT, "bad prim_kind");
+        if (s->prim_material[p] >= s->n_materials)
+            return fail(RTX_ERR_INVALID_ARGUMENT, "prim_material out of range");
+        if (s->prim_chain[p] >= s->n_chains) return fail(RTX_ERR_INVALID_ARGUMENT, "prim_chain out of range");
+    }
+    for (uint32_t k = 0; k < s->n_steps; ++k)
+        if (s->step_kind[k] > RTX_STEP_ROTATE) return fail(RTX_ERR_INVALID_ARGUMENT, "bad step_kind");
+    for (uint32_t m = 0; m < s->n_materials; ++m) {
+        if (s->mat_kind[m] > RTX_MAT_DIFFUSE_LIGHT) return fail(RTX_ERR_INVALID_ARGUMENT, "bad mat_kind");
+        if (s->mat_kind[m] != RTX_MAT_DIELECTRIC && s->mat_texture[m] >= s->n_textures)
+            return fail(RTX_ERR_INVALID_ARGUMENT, "mat_texture out of range");
+    }
+    for (uint32_t t = 0; t < s->n_textures; ++t) {
+        if (s->tex_kind[t] > RTX_TEX_CHECKER) return fail(RTX_ERR_INVALID_ARGUMENT, "bad tex_kind");
+        if (s->tex_kind[t] == RTX_TEX_CHECKER &&
+            (s->tex_odd[t] >= s->n_textures || s->tex_even[t] >= s->n_textures))
+            return fail(RTX_ERR_INVALID_ARGUMENT, "checker sub-texture out of range");
+    }
+    for (uint32_t l = 0; l < s->n_lights; ++l)
+        if (s->light_kind[l] > RTX_LIGHT_OTHER) return fail(RTX_ERR_INVALID_ARGUMENT, "bad light_kind");
+    if (!s->light_is_list && s->n_lights != 1)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "a bare (non-list) light shape must have exactly one entry");
+    return RTX_OK;
+}
+
+int check_params(const RtxContext* ctx, const RtxParams* p) {
+    if (!ctx) return fail(RTX_ERR_INVALID_ARGUMENT, "context is null");
+    if (!p) return fail(RTX_ERR_INVALID_ARGUMENT, "params is null");
+    if (!ctx->has_scene) return fail(RTX_ERR_NO_SCENE, "no scene uploaded");
+    if (p->width == 0 || p->height == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "empty image");
+    if ((uint64_t)p->width * p->height > (1ull << 30))
+        return fail(RTX_ERR_TOO_LARGE, "more than 2^30 pixels");
+    if (p->mode > RTX_MODE_DETERMINISTIC) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown mode");
+    if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "sample range overflows 32 bits");
+    return RTX_OK;
+}
+
+rtxd::TraceArgs make_trace_args(const RtxContext* ctx, const RtxParams* p) {
+    rtxd::TraceArgs a{};
+    a.scene = ctx->view;
+    a.width = p->width;
+    a.height = p->height;
+    a.spp_begin = p->spp_begin;
+    a.spp_count = p->spp_count;
+    a.max_depth = p->max_depth;
+    a.accumulate = p->accumulate;
+    a.seed = p->seed;
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rtx_last_error(void) { return g_last_error.c_str(); }
+
+int rtx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int rtx_create(int device, RtxContext** out_ctx) {
+    if (!out_ctx) return fail(RTX_ERR_INVALID_ARGUMENT, "out_ctx is null");
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        return fail(RTX_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
+    }
+    if (device < 0 || device >= n) return fail(RTX_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    RTX_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RTX_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(RTX_ERR_NO_DEVICE,
+                    std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    RtxContext* ctx = new (std::nothrow) RtxContext();
+    if (!ctx) return fail(RTX_ERR_HIP, "out of host memory");
+    ctx->device = device;
+    *out_ctx = ctx;
+    return RTX_OK;
+}
+
+void rtx_destroy(RtxContext* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    delete ctx;
+}
+
+int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
+    if (!ctx) return fail(RTX_ERR_INVALID_ARGUMENT, "context is null");
+    if (accel > RTX_ACCEL_BVH) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown accel");
+    int rc = check_scene(s);
+    if (rc != RTX_OK) return rc;
+    RTX_HIP(hipSetDevice(ctx->device));
+    ctx->has_scene = false;
+
+    const bool use_bvh = accel == RTX_ACCEL_BVH || (accel == RTX_ACCEL_AUTO && s->n_prims > 64);
+
+    std::vector<rtxd::Prim> prims(s->n_prims);
+    for (uint32_t p = 0; p < s->n_prims; ++p) {
+        rtxd::Prim& P = prims[p];
+        P.a = s->prim_a[p]; P.b = s->prim_b[p]; P.c = s->prim_c[p]; P.d = s->prim_d[p]; P.e = s->prim_e[p];
+        P.kind = s->prim_kind[p];
+        P.flip = s->prim_flip[p] ? 1u : 0u;
+        P.material = s->prim_material[p];
+    }
+    std::vector<rtxd::Step> steps(s->n_steps);
+    for (uint32_t k = 0; k < s->n_steps; ++k) {
+        rtxd::Step& S = steps[k];
+        S.x = s->step_x[k]; S.y = s->step_y[k]; S.z = s->step_z[k]; S.w = s->step_w[k];
+        S.kind = s->step_kind[k];
+        S.pad[0] = S.pad[1] = S.pad[2] = 0;
+    }
+    // Groups: runs of consecutive primitives under one chain.  For the linear scan a
+    // run of untransformed primitives is one group; for the BVH every untransformed
+    // primitive is its own item so the tree can separate them.
+    std::vector<rtxd::Group> groups;
+    for (uint32_t p = 0; p < s->n_prims;) {
+        uint32_t c = s->prim_chain[p];
+        uint32_t q = p + 1;
+        if (!(use_bvh && c == 0))
+            while (q < s->n_prims && s->prim_chain[q] == c) ++q;
+        groups.push_back(rtxd::Group{p, q, s->chain_begin[c], s->chain_begin[c + 1]});
+        p = q;
+    }
+    std::vector<rtxd::Material> mats(s->n_materials);
+    for (uint32_t m = 0; m < s->n_materials; ++m)
+        mats[m] = rtxd::Material{s->mat_kind[m], s->mat_texture[m], s->mat_param[m], 0u};
+    std::vector<rtxd::Texture> texs(s->n_textures);
+    for (uint32_t t = 0; t < s->n_textures; ++t) {
+        rtxd::Texture& T = texs[t];
+        T.kind = s->tex_kind[t];
+        T.r = s->tex_r[t]; T.g = s->tex_g[t]; T.b = s->tex_b[t];
+        T.odd = s->tex_odd[t]; T.even = s->tex_even[t];
+        T.pad[0] = T.pad[1] = 0;
+    }
+    std::vector<rtxd::Light> lights(s->n_lights);
+    for (uint32_t l = 0; l < s->n_lights; ++l) {
+        rtxd::Light& E = lights[l];
+        E.a = s->light_a[l]; E.b = s->light_b[l]; E.c = s->light_c[l]; E.d = s->light_d[l]; E.e = s->light_e[l];
+        E.kind = s->light_kind[l];
+        E.pad[0] = E.pad[1] = 0;
+    }
+    std::vector<rtxd::BvhNode> nodes;
+    std::vector<uint32_t> items;
+    if (use_bvh) {
+        std::string err;
+        if (!rtxbvh::build(prims, groups, steps, nodes, items, err)) return fail(RTX_ERR_TOO_LARGE, err);
+    }
+
+    RTX_HIP(ctx->prims.upload(prims));
+    RTX_HIP(ctx->groups.upload(groups));
+    RTX_HIP(ctx->steps.upload(steps));
+    RTX_HIP(ctx->materials.upload(mats));
+    RTX_HIP(ctx->textures.upload(texs));
+    RTX_HIP(ctx->lights.upload(lights));
+    RTX_HIP(ctx->bvh.upload(nodes));
+    RTX_HIP(ctx->bvh_items.upload(items));
+
+    rtxd::SceneView& v = ctx->view;
+    v.prims = ctx->prims.ptr;
+    v.groups = ctx->groups.ptr;
+    v.steps = ctx->steps.ptr;
+    v.materials = ctx->materials.ptr;
+    v.textures = ctx->textures.ptr;
+    v.lights = ctx->lights.ptr;
+    v.bvh = use_bvh ? ctx->bvh.ptr : nullptr;
+    v.bvh_items = use_bvh ? ctx->bvh_items.ptr : nullptr;
+    v.n_prims = s->n_prims;
+    v.n_groups = (uint32_t)groups.size();
+    v.n_steps = s->n_steps;
+    v.n_materials = s->n_materials;
+    v.n_textures = s->n_textures;
+    v.n_lights = s->n_lights;
+    v.n_bvh_nodes = (uint32_t)nodes.size();
+    v.light_is_list = s->light_is_list ? 1u : 0u;
+    std::memcpy(v.cam_origin, s->cam_origin, sizeof v.cam_origin);
+    std::memcpy(v.cam_ll, s->cam_ll, sizeof v.cam_ll);
+    std::memcpy(v.cam_u, s->cam_u, sizeof v.cam_u);
+    std::memcpy(v.cam_v, s->cam_v, sizeof v.cam_v);
+    std::memcpy(v.background, s->background, sizeof v.background);
+
+    ctx->info.n_prims = s->n_prims;
+    ctx->info.n_items = (uint32_t)groups.size();
+    ctx->info.n_bvh_nodes = (uint32_t)nodes.size();
+    ctx->info.accel = use_bvh ? RTX_ACCEL_BVH : RTX_ACCEL_LINEAR;
+    ctx->has_scene = true;
+    return RTX_OK;
+}
+
+int rtx_scene_info(RtxContext* ctx, RtxSceneInfo* out) {
+    if (!ctx || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ctx->has_scene) return fail(RTX_ERR_NO_SCENE, "no scene uploaded");
+    *out = ctx->info;
+    return RTX_OK;
+}
+
+int rtx_render_device(RtxContext* ctx, const RtxParams* params, float* d_accum_rgb,
+                      unsigned long long* d_rays, void* hip_stream) {
+    int rc = check_params(ctx, params);
+    if (rc != RTX_OK) return rc;
+    if (!d_accum_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "accumulator is null");
+    RTX_HIP(hipSetDevice(ctx->device));
+    rtxd::TraceArgs a = make_trace_args(ctx, params);
+    a.accum = d_accum_rgb;
+    a.rays = d_rays;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (params->mode == RTX_MODE_DETERMINISTIC) RTX_HIP(rtx_det_mode::launch_trace(a, stream));
+    else RTX_HIP(rtx_fast_mode::launch_trace(a, stream));
+    return RTX_OK;
+}
+
+int rtx_render(RtxContext* ctx, const RtxParams* params, float* accum_rgb, uint64_t* rays_out) {
+    int rc = check_params(ctx, params);
+    if (rc != RTX_OK) return rc;
+    if (!accum_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "accumulator is null");
+    RTX_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)params->width * params->height * 3;
+    RTX_HIP(ctx->accum.resize(n));
+    RTX_HIP(ctx->rays.resize(1));
+    if (params->accumulate)
+        RTX_HIP(hipMemcpy(ctx->accum.ptr, accum_rgb, n * sizeof(float), hipMemcpyHostToDevice));
+    RTX_HIP(hipMemset(ctx->rays.ptr, 0, sizeof(unsigned long long)));
+    rc = rtx_render_device(ctx, params, ctx->accum.ptr, ctx->rays.ptr, nullptr);
+    if (rc != RTX_OK) return rc;
+    RTX_HIP(hipDeviceSynchronize());
+    RTX_HIP(hipMemcpy(accum_rgb, ctx->accum.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (rays_out) {
+        unsigned long long r = 0;
+        RTX_HIP(hipMemcpy(&r, ctx->rays.ptr, sizeof r, hipMemcpyDeviceToHost));
+        *rays_out = r;
+    }
+    return RTX_OK;
+}
+
+int rtx_render_samples(RtxContext* ctx, const RtxParams* params, float* sample_rgb,
+                       uint32_t* sample_segments) {
+    int rc = check_params(ctx, params);
+    if (rc != RTX_OK) return rc;
+    if (!sample_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "sample_rgb is null");
+    const uint64_t n_samples = (uint64_t)params->width * params->height * params->spp_count;
+    if (n_samples > (1ull << 28)) return fail(RTX_ERR_TOO_LARGE, "per-sample output limited to 2^28 samples");
+    if (n_samples == 0) return RTX_OK;
+    RTX_HIP(hipSetDevice(ctx->device));
+    RTX_HIP(ctx->sample_rgb.resize(n_samples * 3));
+    RTX_HIP(ctx->sample_segments.resize(n_samples));
+    rtxd::TraceArgs a = make_trace_args(ctx, params);
+    a.sample_rgb = ctx->sample_rgb.ptr;
+    a.sample_segments = ctx->sample_segments.ptr;
+    if (params->mode == RTX_MODE_DETERMINISTIC) RTX_HIP(rtx_det_mode::launch_trace(a, nullptr));
+    else RTX_HIP(rtx_fast_mode::launch_trace(a, nullptr));
+    RTX_HIP(hipDeviceSynchronize());
+    RTX_HIP(hipMemcpy(sample_rgb, ctx->sample_rgb.ptr, n_samples * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (sample_segments)
+        RTX_HIP(hipMemcpy(sample_segments, ctx->sample_segments.ptr, n_samples * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_hit(RtxContext* ctx, uint32_t n, const float* origins, const float* directions, float t0,
+            float t1, uint32_t mode, RtxHit* hits) {
+    if (!ctx) return fail(RTX_ERR_INVALID_ARGUMENT, "context is null");
+    if (!ctx->has_scene) return fail(RTX_ERR_NO_SCENE, "no scene uploaded");
+    if (mode > RTX_MODE_DETERMINISTIC) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown mode");
+    if (n == 0) return RTX_OK;
+    if (!origins || !directions || !hits) return fail(RTX_ERR_INVALID_ARGUMENT, "null ray / hit array");
+    if (n > (1u << 28)) return fail(RTX_ERR_TOO_LARGE, "more than 2^28 rays");
+    RTX_HIP(hipSetDevice(ctx->device));
+    RTX_HIP(ctx->ray_o.resize((size_t)n * 3));
+    RTX_HIP(ctx->ray_d.resize((size_t)n * 3));
+    RTX_HIP(ctx->hits.resize(n));
+    RTX_HIP(hipMemcpy(ctx->ray_o.ptr, origins, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    RTX_HIP(hipMemcpy(ctx->ray_d.ptr, directions, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    rtxd::HitArgs a{};
+    a.scene = ctx->view;
+    a.n = n;
+    a.t0 = t0;
+    a.t1 = t1;
+    a.origins = ctx->ray_o.ptr;
+    a.directions = ctx->ray_d.ptr;
+    a.hits = ctx->hits.ptr;
+    if (mode == RTX_MODE_DETERMINISTIC) RTX_HIP(rtx_det_mode::launch_hit(a, nullptr));
+    else RTX_HIP(rtx_fast_mode::launch_hit(a, nullptr));
+    RTX_HIP(hipDeviceSynchronize());
+    RTX_HIP(hipMemcpy(hits, ctx->hits.ptr, (size_t)n * sizeof(RtxHit), hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_resolve_device(RtxContext* ctx, uint32_t width, uint32_t height, uint32_t ns,
+                       const float* d_accum_rgb, uint8_t* rgb8, void* hip_stream) {
+    if (!ctx) return fail(RTX_ERR_INVALID_ARGUMENT, "context is null");
+    if (!d_accum_rgb || !rgb8) return fail(RTX_ERR_INVALID_ARGUMENT, "null buffer");
+    if (width == 0 || height == 0 || ns == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "empty image or ns == 0");
+    if ((uint64_t)width * height > (1ull << 30)) return fail(RTX_ERR_TOO_LARGE, "more than 2^30 pixels");
+    RTX_HIP(hipSetDevice(ctx->device));
+    const uint32_t n_pixels = width * height;
+    RTX_HIP(ctx->rgb8.resize((size_t)n_pixels * 3));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    RTX_HIP(rtx_post::launch_resolve(d_accum_rgb, ctx->rgb8.ptr, n_pixels, ns, stream));
+    RTX_HIP(hipMemcpyAsync(rgb8, ctx->rgb8.ptr, (size_t)n_pixels * 3, hipMemcpyDeviceToHost, stream));
+    RTX_HIP(hipStreamSynchronize(stream));
+    return RTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,231 @@
+// rtx_bvh.cpp — binned-SAH top-down BVH build over scene groups (host, C++17).
+#include "rtx_bvh.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+#include "rtx.h"
+
+namespace rtxbvh {
+namespace {
+
+struct Box {
+    double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX};
+    double hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    void add(const double p[3]) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], p[a]);
+            hi[a] = std::max(hi[a], p[a]);
+        }
+    }
+    void add(const Box& b) {
+        add(b.lo);
+        add(b.hi);
+    }
+    double area() const {
+        double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0;
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+void quat_rotate(const rtxd::Step& q, double v[3]) {
+    // v' = q v q*, expanded in double precision (bounds only; not on the hit path)
+    double x = q.x, y = q.y, z = q.z, w = q.w;
+    double tx = w * v[0] + y * v[2] - z * v[1];
+    double ty = w * v[1] + z * v[0] - x * v[2];
+    double tz = w * v[2] + x * v[1] - y * v[0];
+    double tw = x * v[0] + y * v[1] + z * v[2];
+    double rx = tw * x + tx * w - ty * z + tz * y;
+    double ry = tw * y + ty * w - tz * x + tx * z;
+    double rz = tw * z + tz * w - tx * y + ty * x;
+    v[0] = rx;
+    v[1] = ry;
+    v[2] = rz;
+}
+
+Box prim_box(const rtxd::Prim& P) {
+    Box b;
+    if (P.kind == RTX_PRIM_SPHERE) {
+        double r = std::fabs((double)P.d);
+        double lo[3] = {P.a - r, P.b - r, P.c - r}, hi[3] = {P.a + r, P.b + r, P.c + r};
+        b.add(lo);
+        b.add(hi);
+        return b;
+    }
+    int xi, yi, zi;
+    if (P.kind == RTX_PRIM_RECT_XY) { xi = 0; yi = 1; zi = 2; }
+    else if (P.kind == RTX_PRIM_RECT_XZ) { xi = 0; yi = 2; zi = 1; }
+    else { xi = 1; yi = 2; zi = 0; }
+    double lo[3], hi[3];
+    lo[xi] = std::min(P.a, P.b); hi[xi] = std::max(P.a, P.b);
+    lo[yi] = std::min(P.c, P.d); hi[yi] = std::max(P.c, P.d);
+    lo[zi] = hi[zi] = P.e;
+    b.add(lo);
+    b.add(hi);
+    return b;
+}
+
+Box group_box(const std::vector<rtxd::Prim>& prims, const rtxd::Group& G,
+              const std::vector<rtxd::Step>& steps) {
+    Box local;
+    for (uint32_t p = G.prim_begin; p < G.prim_end; ++p) local.add(prim_box(prims[p]));
+    Box world;
+    for (int c = 0; c < 8; ++c) {
+        double v[3] = {(c & 1) ? local.hi[0] : local.lo[0], (c & 2) ? local.hi[1] : local.lo[1],
+                       (c & 4) ? local.hi[2] : local.lo[2]};
+        for (uint32_t s = G.step_end; s > G.step_begin; --s) {  // innermost wrapper first
+            const rtxd::Step& S = steps[s - 1];
+            if (S.kind == RTX_STEP_ROTATE) quat_rotate(S, v);
+            else { v[0] += S.x; v[1] += S.y; v[2] += S.z; }
+        }
+        world.add(v);
+    }
+    // Pad: the traversal's slab test runs in fp32 with approximate reciprocals.
+    for (int a = 0; a < 3; ++a) {
+        double mag = std::max({std::fabs(world.lo[a]), std::fabs(world.hi[a]), world.hi[a] - world.lo[a]});
+        double pad = 4e-4 * mag + 1e-5;
+        world.lo[a] -= pad;
+        world.hi[a] += pad;
+    }
+    return world;
+}
+
+struct BuildItem {
+    Box box;
+    double centre[3];
+    uint32_t group;
+};
+
+struct Task {
+    uint32_t node, begin, end;
+    int depth;
+};
+
+void write_node(rtxd::BvhNode& N, const Box& b, uint32_t left, uint32_t count) {
+    for (int a = 0; a < 3; ++a) {
+        // round outwards when narrowing to fp32
+        N.lo[a] = std::nextafterf((float)b.lo[a], -FLT_MAX);
+        N.hi[a] = std::nextafterf((float)b.hi[a], FLT_MAX);
+    }
+    N.left = left;
+    N.count = count;
+}
+
+}  // namespace
+
+bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,
+           const std::vector<rtxd::Step>& steps, std::vector<rtxd::BvhNode>& nodes,
+           std::vector<uint32_t>& items, std::string& err) {
+    const uint32_t n = (uint32_t)groups.size();
+    nodes.clear();
+    items.clear();
+    if (n == 0) {
+        err = "no groups";
+        return false;
+    }
+    std::vector<BuildItem> it(n);
+    for (uint32_t g = 0; g < n; ++g) {
+        it[g].box = group_box(prims, groups[g], steps);
+        it[g].group = g;
+        for (int a = 0; a < 3; ++a) it[g].centre[a] = 0.5 * (it[g].box.lo[a] + it[g].box.hi[a]);
+    }
+    constexpr uint32_t kLeafItems = 2;
+    constexpr int kBins = 16;
+    nodes.reserve(2 * (size_t)n);
+    nodes.emplace_back();
+    std::vector<Task> todo;
+    todo.push_back(Task{0, 0, n, 0});
+    while (!todo.empty()) {
+        Task t = todo.back();
+        todo.pop_back();
+        Box bounds, cbounds;
+        for (uint32_t k = t.begin; k < t.end; ++k) {
+            bounds.add(it[k].box);
+            cbounds.add(it[k].centre);
+        }
+        const uint32_t count = t.end - t.begin;
+        if (count <= kLeafItems) {
+            write_node(nodes[t.node], bounds, t.begin, count);
+            continue;
+        }
+        if (t.depth >= kMaxDepth) {
+            err = "BVH deeper than the traversal stack allows";
+            return false;
+        }
+        // binned SAH over the widest centroid axis first, then the others
+        int best_axis = -1, best_bin = -1;
+        double best_cost = DBL_MAX;
+        // Once the remaining depth budget only just covers a balanced split, stop
+        // trusting SAH and split at the median.
+        const bool force_median = (1u << std::min(kMaxDepth - t.depth - 1, 31)) < count;
+        if (!force_median) {
+            for (int a = 0; a < 3; ++a) {
+                double lo = cbounds.lo[a], ext = cbounds.hi[a] - cbounds.lo[a];
+                if (!(ext > 0.0)) continue;
+                Box bb[kBins];
+                uint32_t bc[kBins] = {0};
+                for (uint32_t k = t.begin; k < t.end; ++k) {
+                    int b = (int)((it[k].centre[a] - lo) / ext * kBins);
+                    b = std::min(std::max(b, 0), kBins - 1);
+                    bb[b].add(it[k].box);
+                    bc[b]++;
+                }
+                double right_area[kBins];
+                uint32_t right_cnt[kBins];
+                Box acc;
+                uint32_t cnt = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    if (bc[b]) acc.add(bb[b]);
+                    cnt += bc[b];
+                    right_area[b] = acc.area();
+                    right_cnt[b] = cnt;
+                }
+                Box lacc;
+                uint32_t lcnt = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    if (bc[b]) lacc.add(bb[b]);
+                    lcnt += bc[b];
+                    if (lcnt == 0 || right_cnt[b + 1] == 0) continue;
+                    double cost = lacc.area() * lcnt + right_area[b + 1] * right_cnt[b + 1];
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = a;
+                        best_bin = b;
+                    }
+                }
+            }
+        }
+        uint32_t mid;
+        if (best_axis >= 0) {
+            const int a = best_axis;
+            const double lo = cbounds.lo[a], ext = cbounds.hi[a] - cbounds.lo[a];
+            auto first_right = std::partition(it.begin() + t.begin, it.begin() + t.end, [&](const BuildItem& x) {
+                int b = (int)((x.centre[a] - lo) / ext * kBins);
+                b = std::min(std::max(b, 0), kBins - 1);
+                return b <= best_bin;
+            });
+            mid = (uint32_t)(first_right - it.begin());
+        } else {
+            int a = 0;
+            for (int k = 1; k < 3; ++k)
+                if (cbounds.hi[k] - cbounds.lo[k] > cbounds.hi[a] - cbounds.lo[a]) a = k;
+            mid = t.begin + count / 2;
+            std::nth_element(it.begin() + t.begin, it.begin() + mid, it.begin() + t.end,
+                             [a](const BuildItem& x, const BuildItem& y) { return x.centre[a] < y.centre[a]; });
+        }
+        if (mid == t.begin || mid == t.end) mid = t.begin + count / 2;
+        const uint32_t left = (uint32_t)nodes.size();
+        nodes.emplace_back();
+        nodes.emplace_back();
+        write_node(nodes[t.node], bounds, left, 0);
+        todo.push_back(Task{left, t.begin, mid, t.depth + 1});
+        todo.push_back(Task{left + 1, mid, t.end, t.depth + 1});
+    }
+    items.resize(n);
+    for (uint32_t k = 0; k < n; ++k) items[k] = it[k].group;
+    return true;
+}
+
+}  // namespace rtxbvh

@@ -1,0 +1,102 @@
+// rtx_device.h — the scene as it lies in HBM and the kernel argument blocks.
+//
+// The C ABI hands the scene over as struct-of-arrays (include/rtx.h); at upload the
+// library repacks it into 32-byte records.  Every lane of a wave walks the SAME
+// primitive / group / light list, so record fields are fetched with wave-uniform
+// scalar loads (one s_load_dwordx8 per record) and used as SGPR operands; only the
+// per-lane winner of a nearest-hit query is re-read with a vector load.
+#pragma once
+#include <stdint.h>
+
+namespace rtxd {
+
+// One world primitive.  Rect (Rect.h:30): a=x0 b=x1 c=y0 d=y1 e=k.  Sphere
+// (Sphere.h:19-20): a,b,c = centre, d = radius.
+struct alignas(32) Prim {
+    float a, b, c, d, e;
+    uint32_t kind;      // RTX_PRIM_*
+    uint32_t flip;      // FlipNormals parity
+    uint32_t material;  // index into Material[]
+};
+
+// A run of consecutive primitives that share one transform chain.
+struct alignas(16) Group {
+    uint32_t prim_begin, prim_end;
+    uint32_t step_begin, step_end;  // outermost wrapper first
+};
+
+// One Translate (x,y,z = offset) or Rotate (x,y,z,w = unit quaternion) wrapper.
+struct alignas(32) Step {
+    float x, y, z, w;
+    uint32_t kind;  // RTX_STEP_*
+    uint32_t pad[3];
+};
+
+struct alignas(16) Material {
+    uint32_t kind;     // RTX_MAT_*
+    uint32_t texture;  // albedo / emission
+    float param;       // fuzz | refractive index
+    uint32_t pad;
+};
+
+struct alignas(32) Texture {
+    uint32_t kind;  // RTX_TEX_*
+    float r, g, b;  // colour; checker: r = frequency
+    uint32_t odd, even;
+    uint32_t pad[2];
+};
+
+struct alignas(32) Light {
+    float a, b, c, d, e;  // as Prim
+    uint32_t kind;        // RTX_LIGHT_*
+    uint32_t pad[2];
+};
+
+// BVH over top-level items.  Inner node: count == 0, children at `left`, `left+1`.
+// Leaf: items [left, left+count).
+struct alignas(32) BvhNode {
+    float lo[3];
+    uint32_t left;
+    float hi[3];
+    uint32_t count;
+};
+
+// A BVH item: one group (a bare primitive is a group of one with an empty chain).
+struct SceneView {
+    const Prim* prims;
+    const Group* groups;
+    const Step* steps;
+    const Material* materials;
+    const Texture* textures;
+    const Light* lights;
+    const BvhNode* bvh;        // null: linear scan over groups
+    const uint32_t* bvh_items; // group index per BVH leaf slot
+    uint32_t n_prims, n_groups, n_steps, n_materials, n_textures, n_lights, n_bvh_nodes;
+    uint32_t light_is_list;
+    float cam_origin[3], cam_ll[3], cam_u[3], cam_v[3];
+    float background[3];
+};
+
+struct TraceArgs {
+    SceneView scene;
+    uint32_t width, height;
+    uint32_t spp_begin, spp_count;
+    uint32_t max_depth;
+    uint32_t accumulate;
+    uint64_t seed;
+    float* accum;                 // [height][width][3], row 0 = top
+    unsigned long long* rays;     // optional
+    float* sample_rgb;            // optional, [pixel][spp_count][3]
+    uint32_t* sample_segments;    // optional, [pixel][spp_count]
+};
+
+struct HitArgs {
+    SceneView scene;
+    uint32_t n;
+    float t0, t1;
+    const float* origins;
+    const float* directions;
+    void* hits;  // RtxHit[n]
+};
+
+}  // namespace rtxd

@@ -1,0 +1,445 @@
+// raytrace.h — host-side scene-building API of the MI355X path tracer.
+//
+// It keeps the class surface of the reference tracer (Raytrace_C++/Src): Vector3,
+// Camera, the Shape hierarchy (Sphere, Rect, Box, ShapeList, FlipNormals,
+// Translate, Rotate) with its fluent ShapeBuilder, the Material family
+// (Lambertian, Metal, Dielectric, DiffuseLight), the Texture family
+// (ColorTexture, CheckerTexture), Image and Scene — same names, constructor
+// signatures and ownership conventions (shared_ptr for shapes / materials /
+// textures), so scene code written for the reference compiles against it.
+//
+// Unlike the reference, these classes do not trace rays: they record their
+// parameters and flatten themselves into the plain arrays of RtxScene
+// (include/rtx.h); all intersection, scattering and integration happens on the
+// GPU behind the C ABI.  There is no CPU rendering path.
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "rtx.h"
+#include "rtx_det.h"
+
+namespace rt {
+
+#ifndef PI
+#define PI 3.14159265359f   // Util.h:2
+#endif
+#ifndef GAMMA_FACTOR
+#define GAMMA_FACTOR 2.2f   // Util.h:8
+#endif
+
+// ---------------------------------------------------------------------------
+// Vector3 / Quat: the subset of vectormath_aos.h the scene API needs, with the
+// library's operation order (vec_aos.h:263-493, quat_aos.h:348-355).
+// ---------------------------------------------------------------------------
+class Vector3 {
+public:
+    Vector3() : mX(0), mY(0), mZ(0) {}
+    Vector3(float x, float y, float z) : mX(x), mY(y), mZ(z) {}
+    explicit Vector3(float s) : mX(s), mY(s), mZ(s) {}
+    float getX() const { return mX; }
+    float getY() const { return mY; }
+    float getZ() const { return mZ; }
+    float operator[](int i) const { return i == 0 ? mX : (i == 1 ? mY : mZ); }
+    static Vector3 xAxis() { return Vector3(1.0f, 0.0f, 0.0f); }
+    static Vector3 yAxis() { return Vector3(0.0f, 1.0f, 0.0f); }
+    static Vector3 zAxis() { return Vector3(0.0f, 0.0f, 1.0f); }
+    Vector3 operator+(const Vector3& v) const { return Vector3(mX + v.mX, mY + v.mY, mZ + v.mZ); }
+    Vector3 operator-(const Vector3& v) const { return Vector3(mX - v.mX, mY - v.mY, mZ - v.mZ); }
+    Vector3 operator-() const { return Vector3(-mX, -mY, -mZ); }
+    Vector3 operator*(float s) const { return Vector3(mX * s, mY * s, mZ * s); }
+    Vector3 operator/(float s) const { return Vector3(mX / s, mY / s, mZ / s); }
+
+private:
+    float mX, mY, mZ;
+};
+inline Vector3 operator*(float s, const Vector3& v) { return v * s; }
+inline float dot(const Vector3& a, const Vector3& b) {
+    float r = a.getX() * b.getX();
+    r = r + a.getY() * b.getY();
+    r = r + a.getZ() * b.getZ();
+    return r;
+}
+inline float lengthSqr(const Vector3& v) { return dot(v, v); }
+float length(const Vector3& v);
+Vector3 normalize(const Vector3& v);
+inline Vector3 cross(const Vector3& a, const Vector3& b) {
+    return Vector3(a.getY() * b.getZ() - a.getZ() * b.getY(), a.getZ() * b.getX() - a.getX() * b.getZ(),
+                   a.getX() * b.getY() - a.getY() * b.getX());
+}
+inline float radians(float deg) { return (deg / 180.f) * PI; }  // Util.h:24
+
+class Quat {
+public:
+    Quat() : x(0), y(0), z(0), w(1) {}
+    Quat(float x_, float y_, float z_, float w_) : x(x_), y(y_), z(z_), w(w_) {}
+    // quat_aos.h:348-355; sin / cos are the bit-reproducible ones of rtx_det.h
+    static Quat rotation(float radians, const Vector3& unitVec);
+    float x, y, z, w;
+};
+
+// ---------------------------------------------------------------------------
+// flattening
+// ---------------------------------------------------------------------------
+class Material;
+class Shape;
+class Texture;
+typedef std::shared_ptr<Material> MaterialPtr;  // Pch.h:11-18
+typedef std::shared_ptr<Shape> ShapePtr;
+typedef std::shared_ptr<Texture> TexturePtr;
+
+class Camera;
+
+// Owns the arrays an RtxScene points into.
+class FlatScene {
+public:
+    FlatScene();
+    // The view is valid while this object is alive and unmodified.
+    const RtxScene* view();
+
+    struct StepRec { uint32_t kind; float x, y, z, w; };
+    // wrapper state while walking the shape tree
+    struct Cursor {
+        std::vector<StepRec> steps;  // outermost first
+        int chain = 0;               // interned chain id, -1 = not yet interned
+        bool flip = false;
+    };
+
+    uint32_t add_prim(uint32_t kind, float a, float b, float c, float d, float e, const MaterialPtr& m,
+                      Cursor& cur);
+    void add_light(uint32_t kind, float a, float b, float c, float d, float e);
+    uint32_t intern_material(const MaterialPtr& m);
+    uint32_t intern_texture(const TexturePtr& t);
+    uint32_t new_texture(uint32_t kind, float r, float g, float b, uint32_t odd, uint32_t even);
+    uint32_t new_material(uint32_t kind, uint32_t tex, float param);
+    void set_camera(const Camera& cam);
+    void set_background(const Vector3& c);
+    void set_light_is_list(bool v) { m_light_is_list = v; }
+    const std::string& error() const { return m_error; }
+    void fail(const std::string& e) { if (m_error.empty()) m_error = e; }
+
+    std::vector<uint32_t> prim_kind, prim_flip, prim_material, prim_chain;
+    std::vector<float> prim_a, prim_b, prim_c, prim_d, prim_e;
+    std::vector<uint32_t> chain_begin, step_kind;
+    std::vector<float> step_x, step_y, step_z, step_w;
+    std::vector<uint32_t> mat_kind, mat_texture;
+    std::vector<float> mat_param;
+    std::vector<uint32_t> tex_kind, tex_odd, tex_even;
+    std::vector<float> tex_r, tex_g, tex_b;
+    std::vector<uint32_t> light_kind;
+    std::vector<float> light_a, light_b, light_c, light_d, light_e;
+
+private:
+    int intern_chain(Cursor& cur);
+    RtxScene m_view;
+    bool m_light_is_list = true;
+    float m_cam[4][3];
+    float m_background[3];
+    std::map<const Material*, uint32_t> m_mat_ids;
+    std::map<const Texture*, uint32_t> m_tex_ids;
+    std::string m_error;
+};
+
+// ---------------------------------------------------------------------------
+// textures (Texture.h, ColorTexture.h, CheckerTexture.h)
+// ---------------------------------------------------------------------------
+class Texture {
+public:
+    virtual ~Texture() {}
+    virtual uint32_t flatten(FlatScene& f) const = 0;
+};
+
+class ColorTexture : public Texture {
+public:
+    ColorTexture(const Vector3& c) : m_color(c) {}
+    uint32_t flatten(FlatScene& f) const override;
+
+private:
+    Vector3 m_color;
+};
+
+class CheckerTexture : public Texture {
+public:
+    CheckerTexture(const TexturePtr& t0, const TexturePtr& t1, float freq) : m_odd(t0), m_even(t1), m_freq(freq) {}
+    uint32_t flatten(FlatScene& f) const override;
+
+private:
+    TexturePtr m_odd, m_even;
+    float m_freq;
+};
+
+// ---------------------------------------------------------------------------
+// materials (Material.h, Lambertian.h, Metal.h, Dielectric.h, DiffuseLight.h)
+// ---------------------------------------------------------------------------
+class Material {
+public:
+    virtual ~Material() {}
+    virtual uint32_t flatten(FlatScene& f) const = 0;
+    virtual void set_texture(const TexturePtr&) {}
+};
+
+class Lambertian : public Material {
+public:
+    Lambertian(const TexturePtr& a) : m_albedo(a) {}
+    uint32_t flatten(FlatScene& f) const override;
+    void set_texture(const TexturePtr& a) override { m_albedo = a; }
+
+private:
+    TexturePtr m_albedo;
+};
+
+class Metal : public Material {
+public:
+    Metal(const TexturePtr& a, float fuzz) : m_albedo(a), m_fuzz(fuzz) {}
+    uint32_t flatten(FlatScene& f) const override;
+    void set_texture(const TexturePtr& a) override { m_albedo = a; }
+    void set_fuzz(float fuzz) { m_fuzz = fuzz; }
+
+private:
+    TexturePtr m_albedo;
+    float m_fuzz;
+};
+
+class Dielectric : public Material {
+public:
+    Dielectric(float ri) : m_ri(ri) {}
+    uint32_t flatten(FlatScene& f) const override;
+
+private:
+    float m_ri;
+};
+
+class DiffuseLight : public Material {
+public:
+    DiffuseLight(const TexturePtr& emit) : m_emit(emit) {}
+    uint32_t flatten(FlatScene& f) const override;
+
+private:
+    TexturePtr m_emit;
+};
+
+// ---------------------------------------------------------------------------
+// shapes (Shape.h, Sphere.h, Rect.h, Box.h, ShapeList.h, FlipNormals.h,
+// Translate.h, Rotate.h)
+// ---------------------------------------------------------------------------
+class Shape {
+public:
+    virtual ~Shape() {}
+    // Emit this shape's leaves, in the order the reference's hit() visits them.
+    virtual void flatten(FlatScene& f, FlatScene::Cursor& cur) const = 0;
+    // Emit this shape as ONE entry of a light list.  Only Rect and Sphere override
+    // pdf_value() / random() in the reference (Shape.h:8-9); everything else keeps
+    // the defaults.
+    virtual void flatten_light(FlatScene& f) const { f.add_light(RTX_LIGHT_OTHER, 0, 0, 0, 0, 0); }
+    virtual bool is_list() const { return false; }
+};
+
+class Sphere : public Shape {
+public:
+    Sphere() : m_radius(0) {}
+    Sphere(const Vector3& c, float r, const MaterialPtr& mat) : m_center(c), m_radius(r), m_material(mat) {}
+    void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
+    void flatten_light(FlatScene& f) const override;
+
+private:
+    Vector3 m_center;
+    float m_radius;
+    MaterialPtr m_material;
+};
+
+class Rect : public Shape {
+public:
+    enum AxisType { kXY = 0, kXZ, kYZ };
+    Rect() : m_x0(0), m_x1(0), m_y0(0), m_y1(0), m_k(0), m_axis(kXY) {}
+    Rect(float x0, float x1, float y0, float y1, float k, AxisType axis, const MaterialPtr& m)
+        : m_x0(x0), m_x1(x1), m_y0(y0), m_y1(y1), m_k(k), m_axis(axis), m_material(m) {}
+    void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
+    void flatten_light(FlatScene& f) const override;
+
+private:
+    float m_x0, m_x1, m_y0, m_y1, m_k;
+    AxisType m_axis;
+    MaterialPtr m_material;
+};
+
+class ShapeList : public Shape {
+public:
+    ShapeList() {}
+    void add(const ShapePtr& shape) { m_list.push_back(shape); }
+    size_t size() const { return m_list.size(); }
+    void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
+    void flatten_light(FlatScene& f) const override;
+    bool is_list() const override { return true; }
+    // Emit the entries of this list as the scene's light list.
+    void flatten_as_light_list(FlatScene& f) const;
+
+private:
+    std::vector<ShapePtr> m_list;
+};
+
+class Box : public Shape {
+public:
+    Box() {}
+    Box(const Vector3& p0, const Vector3& p1, const MaterialPtr& m);
+    void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
+
+private:
+    Vector3 m_p0, m_p1;
+    std::unique_ptr<ShapeList> m_list;
+};
+
+class FlipNormals : public Shape {
+public:
+    FlipNormals(const ShapePtr& shape) : m_shape(shape) {}
+    void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
+
+private:
+    ShapePtr m_shape;
+};
+
+class Translate : public Shape {
+public:
+    Translate(const ShapePtr& sp, const Vector3& displacement) : m_shape(sp), m_offset(displacement) {}
+    void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
+
+private:
+    ShapePtr m_shape;
+    Vector3 m_offset;
+};
+
+class Rotate : public Shape {
+public:
+    Rotate(const ShapePtr& sp, const Vector3& axis, float angle)
+        : m_shape(sp), m_quat(Quat::rotation(radians(angle), axis)) {}
+    void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
+
+private:
+    ShapePtr m_shape;
+    Quat m_quat;
+};
+
+// Fluent factory, ShapeBuilder.h:10-95.
+class ShapeBuilder {
+public:
+    ShapeBuilder() {}
+    ShapeBuilder(const ShapePtr& sp) : m_ptr(sp) {}
+    ShapeBuilder& reset(const ShapePtr& sp) { m_ptr = sp; return *this; }
+    ShapeBuilder& sphere(const Vector3& c, float r, const MaterialPtr& m);
+    ShapeBuilder& rect(float x0, float x1, float y0, float y1, float k, Rect::AxisType axis, const MaterialPtr& m);
+    ShapeBuilder& rectXY(float x0, float x1, float y0, float y1, float k, const MaterialPtr& m);
+    ShapeBuilder& rectXZ(float x0, float x1, float y0, float y1, float k, const MaterialPtr& m);
+    ShapeBuilder& rectYZ(float x0, float x1, float y0, float y1, float k, const MaterialPtr& m);
+    // corner-point overloads: the two in-plane coordinates of p0 / p1 are used
+    ShapeBuilder& rect(const Vector3& p0, const Vector3& p1, float k, Rect::AxisType axis, const MaterialPtr& m);
+    ShapeBuilder& rectXY(const Vector3& p0, const Vector3& p1, float k, const MaterialPtr& m);
+    ShapeBuilder& rectXZ(const Vector3& p0, const Vector3& p1, float k, const MaterialPtr& m);
+    ShapeBuilder& rectYZ(const Vector3& p0, const Vector3& p1, float k, const MaterialPtr& m);
+    ShapeBuilder& box(const Vector3& p0, const Vector3& p1, const MaterialPtr& m);
+    ShapeBuilder& flip();
+    ShapeBuilder& translate(const Vector3& t);
+    ShapeBuilder& rotate(const Vector3& axis, float angle);
+    const ShapePtr& get() const { return m_ptr; }
+
+private:
+    ShapePtr m_ptr;
+};
+
+// ---------------------------------------------------------------------------
+// camera (Camera.h)
+// ---------------------------------------------------------------------------
+class Camera {
+public:
+    Camera() {}
+    Camera(const Vector3& u, const Vector3& v, const Vector3& w);
+    Camera(const Vector3& lookfrom, const Vector3& lookat, const Vector3& vup, float vfov, float aspect);
+    const Vector3& origin() const { return m_origin; }
+    const Vector3& horizontal() const { return m_uvw[0]; }
+    const Vector3& vertical() const { return m_uvw[1]; }
+    const Vector3& lowerLeft() const { return m_uvw[2]; }
+
+private:
+    Vector3 m_origin;
+    Vector3 m_uvw[3];
+};
+
+// ---------------------------------------------------------------------------
+// image (Image.h, DenanFilter.h, GammaFilter.h, TonemapFilter.h)
+// ---------------------------------------------------------------------------
+class Image {
+public:
+    struct rgb { unsigned char r, g, b; };
+    Image() : m_width(0), m_height(0) {}
+    Image(int w, int h);
+    int width() const { return m_width; }
+    int height() const { return m_height; }
+    void* pixels() const { return const_cast<rgb*>(m_pixels.data()); }
+    // NaN filter, gamma 1/2.2, clamp, *255.99 truncated (Image.h:30-39)
+    void write(int x, int y, float r, float g, float b);
+    // 24-bit bottom-up BMP, the format stbi_write_bmp produces (Scene.cpp:155)
+    bool save_bmp(const char* path) const;
+
+private:
+    int m_width, m_height;
+    std::vector<rgb> m_pixels;
+};
+
+// ---------------------------------------------------------------------------
+// scene (Scene.h)
+// ---------------------------------------------------------------------------
+class Scene {
+public:
+    Scene(const char* fileName, int width, int height, int sample);
+    virtual ~Scene();
+
+    // Defines camera, world and light list.  The default is the Cornell-box variant
+    // of the reference (Scene.cpp:37-87); override it or use the setters below.
+    virtual void build();
+    // build(), render on the GPU, write the BMP.  Returns false (see lastError())
+    // on failure; the reference's render() returns void and reports nothing.
+    bool render();
+    const char* getFilename() const { return m_filename.c_str(); }
+
+    void setCamera(Camera* cam) { m_camera.reset(cam); }
+    void setWorld(Shape* world) { m_world.reset(world); }
+    void setLight(Shape* light) { m_light.reset(light); }
+    void setBackground(const Vector3& c) { m_backColor = c; }
+    Vector3 background(const Vector3&) const { return m_backColor; }
+
+    // render options the reference fixes at compile time
+    void setMaxDepth(int d) { m_maxDepth = d; }          // MAX_DEPTH, Scene.cpp:9
+    void setSeed(uint64_t s) { m_seed = s; }
+    void setDeterministic(bool d) { m_deterministic = d; }
+    void setDevice(int d) { m_device = d; }
+    void setSamplesPerLaunch(int s) { m_samplesPerLaunch = s; }
+
+    // Flatten camera / world / light into `out`.  False on a scene the GPU path
+    // cannot express (see FlatScene::error()).
+    bool flatten(FlatScene& out) const;
+    const Image& image() const { return *m_image; }
+    const std::string& lastError() const { return m_error; }
+    unsigned long long raysTraced() const { return m_rays; }
+    double renderSeconds() const { return m_seconds; }
+
+protected:
+    std::unique_ptr<Camera> m_camera;
+    std::unique_ptr<Image> m_image;
+    Vector3 m_backColor;
+    std::string m_filename;
+    std::unique_ptr<Shape> m_world;
+    int m_samples;
+    std::unique_ptr<Shape> m_light;
+    int m_maxDepth = 50;
+    uint64_t m_seed = 0;
+    bool m_deterministic = false;
+    int m_device = 0;
+    int m_samplesPerLaunch = 64;
+    std::string m_error;
+    unsigned long long m_rays = 0;
+    double m_seconds = 0.0;
+};
+
+}  // namespace rt

@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """One RtxContext on device 0 for the whole GPU test session."""
+    from raytrace_amd import api
+
+    if api.device_count() < 1:
+        pytest.fail("no HIP device visible: GPU tests must run on the GPU box")
+    ctx = api.Context(0)
+    yield ctx
+    ctx.close()
