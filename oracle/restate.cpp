@@ -1,0 +1,549 @@
+/*
+ * restate.cpp — CPU restatement of the reference path tracer's algorithm over the
+ * flattened scene description (include/rtx.h), in plain C++17.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the renderer links, loads or calls this
+ * file; it exists so that tests/, __graft_entry__.smoke() and the cpu_baseline leg
+ * of bench.py have an independent checker that can travel to machines where the
+ * reference tree itself is absent.  It is pinned against the reference tracer
+ * (oracle/_ref, built from the unmodified reference sources) by the golden
+ * vectors under tests/golden/ and, where oracle/_ref is present, directly.
+ *
+ * It is written independently of the GPU code (recursive integrator, one
+ * primitive at a time, no shared headers except the random-stream / sincos
+ * contract of include/rtx_det.h) and follows the reference function by function;
+ * each function cites the reference lines it restates (paths relative to
+ * Raytrace_C++/Src, vectormath to external/sce_vectormath-master/include/
+ * vectormath/scalar/cpp).
+ *
+ * The arithmetic type is a template parameter: `float` for rendering, `Counted`
+ * for the op-counting build that yields the algorithmic flops per ray used by the
+ * roofline figure (rule: every fp32 add / sub / mul / div / sqrt / sin / cos the
+ * reference performs counts 1; compares, negation, abs, selects and the integer
+ * random stream count 0).
+ */
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "rtx.h"
+#include "rtx_det.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// arithmetic types
+// ---------------------------------------------------------------------------
+thread_local unsigned long long g_flops = 0;
+
+struct Counted {
+    float v;
+    Counted() : v(0) {}
+    Counted(float x) : v(x) {}
+    explicit operator float() const { return v; }
+};
+inline Counted operator+(Counted a, Counted b) { ++g_flops; return Counted(a.v + b.v); }
+inline Counted operator-(Counted a, Counted b) { ++g_flops; return Counted(a.v - b.v); }
+inline Counted operator*(Counted a, Counted b) { ++g_flops; return Counted(a.v * b.v); }
+inline Counted operator/(Counted a, Counted b) { ++g_flops; return Counted(a.v / b.v); }
+inline Counted operator-(Counted a) { return Counted(-a.v); }
+inline bool operator<(Counted a, Counted b) { return a.v < b.v; }
+inline bool operator>(Counted a, Counted b) { return a.v > b.v; }
+inline bool operator>=(Counted a, Counted b) { return a.v >= b.v; }
+
+inline float raw(float x) { return x; }
+inline float raw(Counted x) { return x.v; }
+inline float f_sqrt(float x) { return ::sqrtf(x); }
+inline Counted f_sqrt(Counted x) { ++g_flops; return Counted(::sqrtf(x.v)); }
+inline float f_abs(float x) { return ::fabsf(x); }
+inline Counted f_abs(Counted x) { return Counted(::fabsf(x.v)); }
+inline void f_sincos(float x, float& s, float& c) { rtx_sincosf(x, &s, &c); }
+inline void f_sincos(Counted x, Counted& s, Counted& c) { g_flops += 2; rtx_sincosf(x.v, &s.v, &c.v); }
+inline float f_sin(float x) { return rtx_sinf(x); }
+inline Counted f_sin(Counted x) { ++g_flops; return Counted(rtx_sinf(x.v)); }
+
+const float kPI = 3.14159265359f;   // Util.h:2
+const float kPI2 = 6.28318530718f;  // Util.h:3
+
+template <class F>
+struct Vec {
+    F x, y, z;
+    Vec() : x(0.0f), y(0.0f), z(0.0f) {}
+    Vec(F a, F b, F c) : x(a), y(b), z(c) {}
+    F at(int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+// vec_aos.h:263-353
+template <class F> Vec<F> operator+(const Vec<F>& a, const Vec<F>& b) { return Vec<F>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class F> Vec<F> operator-(const Vec<F>& a, const Vec<F>& b) { return Vec<F>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class F> Vec<F> operator-(const Vec<F>& a) { return Vec<F>(-a.x, -a.y, -a.z); }
+template <class F> Vec<F> operator*(const Vec<F>& a, F s) { return Vec<F>(a.x * s, a.y * s, a.z * s); }
+template <class F> Vec<F> operator/(const Vec<F>& a, F s) { return Vec<F>(a.x / s, a.y / s, a.z / s); }
+template <class F> Vec<F> mul_per_elem(const Vec<F>& a, const Vec<F>& b) { return Vec<F>(a.x * b.x, a.y * b.y, a.z * b.z); }
+// vec_aos.h:451-458
+template <class F> F dot(const Vec<F>& a, const Vec<F>& b) {
+    F r = a.x * b.x;
+    r = r + a.y * b.y;
+    r = r + a.z * b.z;
+    return r;
+}
+template <class F> F length_sqr(const Vec<F>& a) { return dot(a, a); }            // vec_aos.h:460-467
+template <class F> F length(const Vec<F>& a) { return f_sqrt(length_sqr(a)); }    // vec_aos.h:469-472
+template <class F> Vec<F> normalize(const Vec<F>& a) {                             // vec_aos.h:474-485
+    F len_inv = F(1.0f) / f_sqrt(length_sqr(a));
+    return a * len_inv;
+}
+template <class F> Vec<F> cross(const Vec<F>& a, const Vec<F>& b) {               // vec_aos.h:487-494
+    return Vec<F>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// quat_aos.h:400-412
+template <class F> Vec<F> rotate(F qx, F qy, F qz, F qw, const Vec<F>& v) {
+    F tx = ((qw * v.x) + (qy * v.z)) - (qz * v.y);
+    F ty = ((qw * v.y) + (qz * v.x)) - (qx * v.z);
+    F tz = ((qw * v.z) + (qx * v.y)) - (qy * v.x);
+    F tw = ((qx * v.x) + (qy * v.y)) + (qz * v.z);
+    return Vec<F>((((tw * qx) + (tx * qw)) - (ty * qz)) + (tz * qy),
+                  (((tw * qy) + (ty * qw)) - (tz * qx)) + (tx * qz),
+                  (((tw * qz) + (tz * qw)) - (tx * qy)) + (ty * qx));
+}
+
+template <class F>
+struct Hit {  // HitRec.h:3-10
+    F t;
+    Vec<F> p, n;
+    int prim = -1;
+    uint32_t material = 0;
+};
+
+// ---------------------------------------------------------------------------
+// the tracer
+// ---------------------------------------------------------------------------
+template <class F>
+class Tracer {
+public:
+    Tracer(const RtxScene& s, int max_depth) : sc(s), m_max_depth(max_depth) {}
+    RtxRng rng{0u, 1u};
+    unsigned long long segments = 0;
+
+    F draw() { return F(rtx_rng_nextf(&rng)); }  // drand48(), Util.h:10-12
+
+    // Rect::hit, Rect.cpp:6-34 (t only; the record is completed by the caller)
+    bool rect_hit(uint32_t axis, F x0, F x1, F y0, F y1, F k, const Vec<F>& o, const Vec<F>& d, F t0, F t1, F& t_out) const {
+        int xi, yi, zi;
+        switch (axis) {
+            case RTX_PRIM_RECT_XY: xi = 0; yi = 1; zi = 2; break;
+            case RTX_PRIM_RECT_XZ: xi = 0; yi = 2; zi = 1; break;
+            default: xi = 1; yi = 2; zi = 0; break;
+        }
+        F t = (k - o.at(zi)) / d.at(zi);
+        if (t < t0 || t > t1) return false;
+        F x = o.at(xi) + t * d.at(xi);
+        F y = o.at(yi) + t * d.at(yi);
+        if (x < x0 || x > x1 || y < y0 || y > y1) return false;
+        t_out = t;
+        return true;
+    }
+
+    // Sphere::hit, Sphere.cpp:7-36 (t only)
+    bool sphere_hit(const Vec<F>& c, F radius, const Vec<F>& o, const Vec<F>& d, F t0, F t1, F& t_out) const {
+        Vec<F> oc = o - c;
+        F a = dot(d, d);
+        F b = F(2.0f) * dot(oc, d);
+        F cc = dot(oc, oc) - radius * radius;
+        F D = b * b - F(4.0f) * a * cc;
+        if (D > F(0.0f)) {
+            F root = f_sqrt(D);
+            F temp = (-b - root) / (F(2.0f) * a);
+            if (temp < t1 && temp > t0) { t_out = temp; return true; }
+            temp = (-b + root) / (F(2.0f) * a);
+            if (temp < t1 && temp > t0) { t_out = temp; return true; }
+        }
+        return false;
+    }
+
+    // ShapeList::hit (ShapeList.cpp:5-17) over the flattened leaves.  Leaves that share a
+    // transform chain sit under the same Translate / Rotate wrappers in the reference, so
+    // the ray is transformed once per run (Translate.cpp:7, Rotate.cpp:7-9) and a hit found
+    // inside the run is carried back out once (Rotate.cpp:12-13, Translate.cpp:9).
+    bool world_hit(const Vec<F>& o, const Vec<F>& d, F t0, F t1, Hit<F>& rec) {
+        ++segments;
+        F closest = t1;
+        bool any = false;
+        uint32_t p = 0;
+        while (p < sc.n_prims) {
+            const uint32_t chain = sc.prim_chain[p];
+            const uint32_t sb = sc.chain_begin[chain], se = sc.chain_begin[chain + 1];
+            Vec<F> ro = o, rd = d;
+            for (uint32_t s = sb; s < se; ++s) {
+                if (sc.step_kind[s] == RTX_STEP_TRANSLATE) {
+                    ro = ro - Vec<F>(sc.step_x[s], sc.step_y[s], sc.step_z[s]);
+                } else {
+                    F qx = -sc.step_x[s], qy = -sc.step_y[s], qz = -sc.step_z[s], qw = sc.step_w[s];  // conj
+                    ro = rotate(qx, qy, qz, qw, ro);
+                    rd = rotate(qx, qy, qz, qw, rd);
+                }
+            }
+            bool run_hit = false;
+            Hit<F> local;
+            for (; p < sc.n_prims && sc.prim_chain[p] == chain; ++p) {
+                F t;
+                const uint32_t kind = sc.prim_kind[p];
+                bool ok;
+                if (kind == RTX_PRIM_SPHERE)
+                    ok = sphere_hit(Vec<F>(sc.prim_a[p], sc.prim_b[p], sc.prim_c[p]), F(sc.prim_d[p]), ro, rd, t0, closest, t);
+                else
+                    ok = rect_hit(kind, sc.prim_a[p], sc.prim_b[p], sc.prim_c[p], sc.prim_d[p], sc.prim_e[p], ro, rd, t0, closest, t);
+                if (!ok) continue;
+                closest = t;
+                run_hit = true;
+                local.t = t;
+                local.p = ro + rd * t;  // Ray::at, Ray.h:12
+                if (kind == RTX_PRIM_SPHERE) {
+                    local.n = (local.p - Vec<F>(sc.prim_a[p], sc.prim_b[p], sc.prim_c[p])) / F(sc.prim_d[p]);  // Sphere.cpp:19
+                } else {
+                    local.n = Vec<F>(kind == RTX_PRIM_RECT_YZ ? 1.0f : 0.0f, kind == RTX_PRIM_RECT_XZ ? 1.0f : 0.0f,
+                                     kind == RTX_PRIM_RECT_XY ? 1.0f : 0.0f);  // Rect.cpp:11-13,32
+                }
+                if (sc.prim_flip[p]) local.n = -local.n;  // FlipNormals.cpp:8
+                local.prim = (int)p;
+                local.material = sc.prim_material[p];
+            }
+            if (run_hit) {
+                for (uint32_t s = se; s > sb; --s) {
+                    const uint32_t k = s - 1;
+                    if (sc.step_kind[k] == RTX_STEP_TRANSLATE) {
+                        local.p = local.p + Vec<F>(sc.step_x[k], sc.step_y[k], sc.step_z[k]);
+                    } else {
+                        F qx = sc.step_x[k], qy = sc.step_y[k], qz = sc.step_z[k], qw = sc.step_w[k];
+                        local.p = rotate(qx, qy, qz, qw, local.p);
+                        local.n = rotate(qx, qy, qz, qw, local.n);
+                    }
+                }
+                rec = local;
+                any = true;
+            }
+        }
+        return any;
+    }
+
+    // Texture::value: ColorTexture.h:11-13, CheckerTexture.cpp:3-11
+    Vec<F> texture_value(uint32_t tex, const Vec<F>& p) const {
+        if (sc.tex_kind[tex] == RTX_TEX_COLOR) return Vec<F>(sc.tex_r[tex], sc.tex_g[tex], sc.tex_b[tex]);
+        F freq = sc.tex_r[tex];
+        F sines = f_sin(freq * p.x) * f_sin(freq * p.y) * f_sin(freq * p.z);
+        return texture_value(sines < F(0.0f) ? sc.tex_odd[tex] : sc.tex_even[tex], p);
+    }
+
+    struct Basis { Vec<F> u, v, w; };
+    // ONB::build_from_w, ONB.h:27-38
+    Basis basis_from_w(const Vec<F>& n) const {
+        Basis b;
+        b.w = normalize(n);
+        Vec<F> a = (f_abs(b.w.x) > F(0.9f)) ? Vec<F>(0.0f, 1.0f, 0.0f) : Vec<F>(1.0f, 0.0f, 0.0f);
+        b.v = normalize(cross(b.w, a));
+        b.u = cross(b.w, b.v);
+        return b;
+    }
+    // ONB::local, ONB.h:24-26
+    Vec<F> basis_local(const Basis& b, const Vec<F>& a) const { return b.u * a.x + b.v * a.y + b.w * a.z; }
+
+    // Shape::pdf_value of one light entry: Rect.cpp:36-48, Sphere.cpp:38-50, Shape.h:8
+    F light_entry_pdf(uint32_t l, const Vec<F>& o, const Vec<F>& v) const {
+        const uint32_t kind = sc.light_kind[l];
+        if (kind == RTX_LIGHT_RECT_XZ) {
+            F t;
+            if (!rect_hit(RTX_PRIM_RECT_XZ, sc.light_a[l], sc.light_b[l], sc.light_c[l], sc.light_d[l], sc.light_e[l], o, v,
+                          F(0.001f), F(FLT_MAX), t))
+                return F(0.0f);
+            F area = (F(sc.light_b[l]) - F(sc.light_a[l])) * (F(sc.light_d[l]) - F(sc.light_c[l]));
+            F distance_squared = (t * t) * length_sqr(v);
+            F cosine = f_abs(dot(v, Vec<F>(0.0f, 1.0f, 0.0f))) / length(v);
+            return distance_squared / (cosine * area);
+        }
+        if (kind == RTX_LIGHT_SPHERE) {
+            F t;
+            Vec<F> c(sc.light_a[l], sc.light_b[l], sc.light_c[l]);
+            F radius = sc.light_d[l];
+            if (!sphere_hit(c, radius, o, v, F(0.001f), F(FLT_MAX), t)) return F(0.0f);
+            F dd = length_sqr(c - o);
+            F r2 = radius * radius;
+            F rr = dd < r2 ? dd : r2;  // std::min(pow2(m_radius), dd)
+            F cos_theta_max = f_sqrt(F(1.0f) - rr * (F(1.0f) / dd));
+            F solid_angle = F(kPI2) * (F(1.0f) - cos_theta_max);
+            return F(1.0f) / solid_angle;
+        }
+        return F(0.0f);
+    }
+
+    // ShapePdf::value (ShapePdf.h:11-13) -> ShapeList::pdf_value (ShapeList.cpp:19-26)
+    F light_pdf(const Vec<F>& o, const Vec<F>& v) const {
+        if (!sc.light_is_list) return light_entry_pdf(0, o, v);
+        F weight = F(1.0f) / F((float)sc.n_lights);
+        F sum = 0.0f;
+        for (uint32_t l = 0; l < sc.n_lights; ++l) sum = sum + weight * light_entry_pdf(l, o, v);
+        return sum;
+    }
+
+    // Shape::random of one light entry: Rect.cpp:50-68, Sphere.cpp:52-58 (+ Util.h:96-107), Shape.h:9
+    Vec<F> light_entry_random(uint32_t l, const Vec<F>& o) {
+        const uint32_t kind = sc.light_kind[l];
+        if (kind == RTX_LIGHT_RECT_XZ) {
+            F x = F(sc.light_a[l]) + draw() * (F(sc.light_b[l]) - F(sc.light_a[l]));
+            F y = F(sc.light_c[l]) + draw() * (F(sc.light_d[l]) - F(sc.light_c[l]));
+            return Vec<F>(x, sc.light_e[l], y) - o;
+        }
+        if (kind == RTX_LIGHT_SPHERE) {
+            Vec<F> direction = Vec<F>(sc.light_a[l], sc.light_b[l], sc.light_c[l]) - o;
+            F distance_squared = length_sqr(direction);
+            Basis uvw = basis_from_w(direction);
+            F radius = sc.light_d[l];
+            F r1 = draw();
+            F r2 = draw();
+            F rad2 = radius * radius;
+            F rr = distance_squared < rad2 ? distance_squared : rad2;
+            F cos_theta_max = f_sqrt(F(1.0f) - rr * (F(1.0f) / distance_squared));
+            F z = F(1.0f) - r2 * (F(1.0f) - cos_theta_max);
+            F sqrtz = f_sqrt(F(1.0f) - z * z);
+            F phi = F(kPI2) * r1;
+            F sn, cs;
+            f_sincos(phi, sn, cs);
+            return basis_local(uvw, Vec<F>(cs * sqrtz, sn * sqrtz, z));
+        }
+        return Vec<F>(1.0f, 0.0f, 0.0f);
+    }
+
+    // ShapePdf::generate (ShapePdf.h:15-17) -> ShapeList::random (ShapeList.cpp:28-35)
+    Vec<F> light_random(const Vec<F>& o) {
+        if (!sc.light_is_list) return light_entry_random(0, o);
+        size_t n = sc.n_lights;
+        size_t index = size_t(raw(draw()) * (float)n);
+        if (n > 0 && index >= n) index = n - 1;
+        return light_entry_random((uint32_t)index, o);
+    }
+
+    // Scene::color, Scene.cpp:103-132
+    Vec<F> color(const Vec<F>& o, const Vec<F>& d, int depth) {
+        Hit<F> rec;
+        if (!world_hit(o, d, F(0.001f), F(FLT_MAX), rec))
+            return Vec<F>(sc.background[0], sc.background[1], sc.background[2]);
+        const uint32_t m = rec.material;
+        const uint32_t kind = sc.mat_kind[m];
+        // Material::emitted: Material.h:10, DiffuseLight.h:21-28
+        Vec<F> emitted(0.0f, 0.0f, 0.0f);
+        if (kind == RTX_MAT_DIFFUSE_LIGHT && dot(rec.n, d) < F(0.0f)) emitted = texture_value(sc.mat_texture[m], rec.p);
+        if (!(depth < m_max_depth)) return emitted;
+        switch (kind) {
+            case RTX_MAT_DIFFUSE_LIGHT:  // DiffuseLight.h:17-19: scatter() is false
+                return emitted;
+            case RTX_MAT_METAL: {  // Metal.cpp:9-17
+                Vec<F> nd = normalize(d);
+                Vec<F> reflected = nd - rec.n * (F(2.0f) * dot(nd, rec.n));  // reflect, Util.h:56-58
+                Vec<F> q;
+                do {  // random_in_unit_sphere, Util.h:32-38; g++ evaluates the arguments of
+                      // Vector3(drand48(), drand48(), drand48()) (Util.h:28-30) right to left
+                    F rz = draw();
+                    F ry = draw();
+                    F rx = draw();
+                    q = Vec<F>(rx, ry, rz) * F(2.0f) - Vec<F>(1.0f, 1.0f, 1.0f);
+                } while (length_sqr(q) >= F(1.0f));
+                reflected = reflected + q * F(sc.mat_param[m]);
+                Vec<F> albedo = texture_value(sc.mat_texture[m], rec.p);
+                if (!(dot(reflected, rec.n) > F(0.0f))) return emitted;
+                return emitted + mul_per_elem(albedo, color(rec.p, reflected, depth + 1));  // Scene.cpp:110
+            }
+            case RTX_MAT_DIELECTRIC: {  // Dielectric.cpp:7-45
+                F ri = sc.mat_param[m];
+                Vec<F> reflected = d - rec.n * (F(2.0f) * dot(d, rec.n));
+                Vec<F> outward;
+                F ni_over_nt, cosine;
+                if (dot(d, rec.n) > F(0.0f)) {
+                    outward = -rec.n;
+                    ni_over_nt = ri;
+                    cosine = ri * dot(d, rec.n) / length(d);
+                } else {
+                    outward = rec.n;
+                    ni_over_nt = F(1.0f) / ri;
+                    cosine = -dot(d, rec.n) / length(d);
+                }
+                // refract(-d, outward, ni_over_nt), Util.h:60-71
+                Vec<F> refracted;
+                F reflect_prob = 1.0f;
+                {
+                    Vec<F> uv = normalize(-d);
+                    F dt = dot(uv, outward);
+                    F D = F(1.0f) - (ni_over_nt * ni_over_nt) * (F(1.0f) - dt * dt);
+                    if (D > F(0.0f)) {
+                        refracted = (uv - outward * dt) * (-ni_over_nt) - outward * f_sqrt(D);
+                        // schlick, Util.h:73-76
+                        F q = (F(1.0f) - ri) / (F(1.0f) + ri);
+                        F r0 = q * q;
+                        F mm = F(1.0f) - cosine;
+                        reflect_prob = r0 + (F(1.0f) - r0) * (mm * mm * mm * mm * mm);
+                    }
+                }
+                Vec<F> dir = (draw() < reflect_prob) ? reflected : refracted;
+                // albedo (1,1,1): mulPerElem by one (Scene.cpp:110)
+                return emitted + mul_per_elem(Vec<F>(1.0f, 1.0f, 1.0f), color(rec.p, dir, depth + 1));
+            }
+            default: {  // Lambertian.cpp:16-25 + Scene.cpp:112-125
+                Vec<F> albedo = texture_value(sc.mat_texture[m], rec.p);
+                Vec<F> dir;
+                if (draw() < F(0.5f)) {  // MixturePdf::generate, MixturePdf.h:15-22
+                    dir = light_random(rec.p);
+                } else {  // CosinePdf::generate (CosinePdf.cpp:16-20), random_cosine_direction (Util.h:86-94)
+                    Basis uvw = basis_from_w(rec.n);
+                    F r1 = draw();
+                    F r2 = draw();
+                    F z = f_sqrt(F(1.0f) - r2);
+                    F phi = F(kPI2) * r1;
+                    F sn, cs;
+                    f_sincos(phi, sn, cs);
+                    F x = cs * f_sqrt(r2);
+                    F y = sn * f_sqrt(r2);
+                    dir = basis_local(uvw, Vec<F>(x, y, z));
+                }
+                // MixturePdf::value, MixturePdf.h:9-13
+                F pdf0 = light_pdf(rec.p, dir);
+                F cosine = dot(normalize(dir), rec.n);  // CosinePdf::value, CosinePdf.cpp:6-14
+                F pdf1 = cosine > F(0.0f) ? cosine / F(kPI) : F(0.0f);
+                F pdf_value = F(0.5f) * pdf0 + F(0.5f) * pdf1;
+                if (!(pdf_value > F(0.0f))) return emitted;
+                F c2 = dot(rec.n, normalize(dir));  // Lambertian::scattering_pdf, Lambertian.cpp:23-25
+                F spdf = (c2 < F(0.0f) ? F(0.0f) : c2) / F(kPI);
+                Vec<F> weight = albedo * spdf;
+                return emitted + mul_per_elem(weight, color(rec.p, dir, depth + 1)) / pdf_value;  // Scene.cpp:120
+            }
+        }
+    }
+
+    // one sample of Scene::render's inner loop, Scene.cpp:145-148 (+ Camera::getRay, Camera.h:24-26)
+    Vec<F> sample(int i, int j, int nx, int ny) {
+        F u = (F((float)i) + draw()) / F((float)nx);
+        F v = (F((float)j) + draw()) / F((float)ny);
+        Vec<F> org(sc.cam_origin[0], sc.cam_origin[1], sc.cam_origin[2]);
+        Vec<F> ll(sc.cam_ll[0], sc.cam_ll[1], sc.cam_ll[2]);
+        Vec<F> hu(sc.cam_u[0], sc.cam_u[1], sc.cam_u[2]);
+        Vec<F> hv(sc.cam_v[0], sc.cam_v[1], sc.cam_v[2]);
+        Vec<F> dir = ll + hu * u + hv * v - org;
+        return color(org, dir, 0);
+    }
+
+private:
+    const RtxScene& sc;
+    int m_max_depth;
+};
+
+template <class F>
+int render_impl(const RtxScene* scene, int nx, int ny, int spp_begin, int spp_count, uint64_t seed, int max_depth,
+                int n_threads, float* sum_rgb, float* per_sample_rgb, uint32_t* per_sample_segments,
+                uint64_t* total_rays, uint64_t* total_flops) {
+    if (!scene || nx <= 0 || ny <= 0 || spp_count < 0) return -1;
+    std::atomic<int> next_row(0);
+    std::atomic<unsigned long long> rays(0), flops(0);
+    auto worker = [&]() {
+        Tracer<F> tr(*scene, max_depth);
+        g_flops = 0;
+        for (;;) {
+            int j = next_row.fetch_add(1);
+            if (j >= ny) break;
+            for (int i = 0; i < nx; ++i) {
+                Vec<F> c(0.0f, 0.0f, 0.0f);
+                const uint32_t pixel = uint32_t(j) * uint32_t(nx) + uint32_t(i);
+                for (int s = 0; s < spp_count; ++s) {
+                    rtx_rng_init(&tr.rng, pixel, uint32_t(spp_begin + s), seed);
+                    unsigned long long before = tr.segments;
+                    Vec<F> L = tr.sample(i, j, nx, ny);
+                    c = c + L;  // Scene.cpp:148
+                    const size_t k = size_t(pixel) * spp_count + s;
+                    if (per_sample_rgb) {
+                        per_sample_rgb[3 * k + 0] = raw(L.x);
+                        per_sample_rgb[3 * k + 1] = raw(L.y);
+                        per_sample_rgb[3 * k + 2] = raw(L.z);
+                    }
+                    if (per_sample_segments) per_sample_segments[k] = uint32_t(tr.segments - before);
+                }
+                if (sum_rgb) {
+                    float* o = sum_rgb + (size_t(ny - j - 1) * nx + i) * 3;  // Scene.cpp:151
+                    o[0] = raw(c.x);
+                    o[1] = raw(c.y);
+                    o[2] = raw(c.z);
+                }
+            }
+        }
+        rays += tr.segments;
+        flops += g_flops;
+    };
+    if (n_threads <= 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(worker);
+        for (auto& t : pool) t.join();
+    }
+    if (total_rays) *total_rays = rays.load();
+    if (total_flops) *total_flops = flops.load();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* Same contract as ref_render() of oracle/ref_driver.cpp, over a flattened scene. */
+int restate_render(const RtxScene* scene, int nx, int ny, int spp_begin, int spp_count, uint64_t seed, int max_depth,
+                   int n_threads, float* sum_rgb, float* per_sample_rgb, uint32_t* per_sample_segments,
+                   uint64_t* total_rays) {
+    return render_impl<float>(scene, nx, ny, spp_begin, spp_count, seed, max_depth, n_threads, sum_rgb, per_sample_rgb,
+                              per_sample_segments, total_rays, nullptr);
+}
+
+/* Op-counting run: total fp32 operations and rays of the same render. */
+int restate_count_flops(const RtxScene* scene, int nx, int ny, int spp_begin, int spp_count, uint64_t seed,
+                        int max_depth, int n_threads, uint64_t* total_rays, uint64_t* total_flops) {
+    return render_impl<Counted>(scene, nx, ny, spp_begin, spp_count, seed, max_depth, n_threads, nullptr, nullptr, nullptr,
+                                total_rays, total_flops);
+}
+
+/* Nearest hit of n rays (Shape::hit of the world). */
+int restate_hit(const RtxScene* scene, uint32_t n, const float* org, const float* dir, float t0, float t1, RtxHit* hits) {
+    if (!scene) return -1;
+    Tracer<float> tr(*scene, 50);
+    for (uint32_t k = 0; k < n; ++k) {
+        Hit<float> rec;
+        Vec<float> o(org[3 * k], org[3 * k + 1], org[3 * k + 2]), d(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);
+        bool h = tr.world_hit(o, d, t0, t1, rec);
+        RtxHit& out = hits[k];
+        std::memset(&out, 0, sizeof out);
+        out.hit = h ? 1 : 0;
+        out.prim = h ? rec.prim : -1;
+        out.material = h ? (int32_t)rec.material : -1;
+        if (h) {
+            out.t = rec.t;
+            out.p[0] = rec.p.x; out.p[1] = rec.p.y; out.p[2] = rec.p.z;
+            out.n[0] = rec.n.x; out.n[1] = rec.n.y; out.n[2] = rec.n.z;
+        }
+    }
+    return 0;
+}
+
+/* Image::write (Image.h:30-39) with its three filters: DenanFilter.h:8-13,
+ * GammaFilter.h:7-9 (Util.h:41-47), TonemapFilter.h:8-10. */
+void restate_image_write(int n, const float* rgb, uint8_t* out) {
+    for (int k = 0; k < n; ++k) {
+        float c[3] = {rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2]};
+        c[0] = !(c[0] == c[0]) ? 1.0f : c[0];
+        c[1] = !(c[1] == c[1]) ? 0.0f : c[1];
+        c[2] = !(c[2] == c[2]) ? 1.0f : c[2];
+        for (int a = 0; a < 3; ++a) {
+            float g = ::powf(c[a], 1.0f / 2.2f);
+            g = (g > 0.0f) ? g : 0.0f;   // maxPerElem(c, 0), vec_aos.h:418-425
+            g = (g < 1.0f) ? g : 1.0f;   // minPerElem(., 1), vec_aos.h:435-442
+            out[3 * k + a] = static_cast<unsigned char>(g * 255.99f);
+        }
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+"""Sample-range sharding across GPUs (one process per GPU, torch.distributed / RCCL).
+
+The path shards naturally over samples: every (pixel, sample) is independent and the
+random stream is keyed by the ABSOLUTE sample index, so ranks render disjoint sample
+ranges of the whole frame into their own fp32 SUM accumulators and one sum-reduce to
+rank 0 combines them.  There is no other exchange step.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Tuple
+
+
+def split_samples(total_spp: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous blocks [begin, begin+count) of a fixed sample budget, one per rank
+    (strong split: the first total_spp % world ranks get one extra sample)."""
+    if total_spp < 0 or world < 1:
+        raise ValueError("bad sample budget / world size")
+    base, extra = divmod(total_spp, world)
+    out, begin = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((begin, n))
+        begin += n
+    return out
+
+
+def step_sample_range(step: int, rank: int, world: int, spp_per_step: int) -> Tuple[int, int]:
+    """Weak split used by progressive rendering: in step k every rank renders
+    spp_per_step new samples; the union over ranks and steps is [0, steps*world*spp)."""
+    if not (0 <= rank < world) or step < 0 or spp_per_step < 0:
+        raise ValueError("bad step / rank")
+    return (step * world + rank) * spp_per_step, spp_per_step
+
+
+def render_frame(render_range: Callable[[int, int], "object"], total_spp: int, rank: int, world: int,
+                 reduce_to_root: Callable[["object"], None] | None = None):
+    """Render this rank's block of `total_spp` samples with `render_range(begin, count)`
+    (which returns the fp32 SUM accumulator tensor of that range) and sum-reduce the
+    accumulators to rank 0.  Returns the accumulator (complete on rank 0)."""
+    begin, count = split_samples(total_spp, world)[rank]
+    accum = render_range(begin, count)
+    if world > 1:
+        if reduce_to_root is None:
+            import torch.distributed as dist
+
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        else:
+            reduce_to_root(accum)
+    return accum

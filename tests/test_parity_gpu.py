@@ -100,3 +100,132 @@ def test_hit_records_match_reference(gpu_ctx):
         assert np.array_equal(got["t"][m], want["t"][m])
         assert np.array_equal(got["p"][m], want["p"][m])
         assert np.array_equal(got["n"][m], want["n"][m])
+
+
+# ---------------------------------------------------------------------------
+# against the committed golden vectors (no reference build needed on the box)
+# ---------------------------------------------------------------------------
+from tests import util  # noqa: E402
+
+
+@pytest.mark.parametrize("key,meta", util.sample_cases())
+@pytest.mark.parametrize("accel", [api.RTX_ACCEL_LINEAR, api.RTX_ACCEL_BVH])
+def test_deterministic_samples_match_golden(gpu_ctx, key, meta, accel):
+    g = util.load_golden(key)
+    scene = api.HostScene(meta["scene"], meta["w"], meta["h"])
+    gpu_ctx.upload(scene, accel)
+    p = gpu_ctx.params(meta["w"], meta["h"], meta["spp_begin"], meta["spp"], mode=api.RTX_MODE_DETERMINISTIC,
+                       seed=meta["seed"])
+    rgb, seg = gpu_ctx.render_samples(p)
+    util.assert_samples_match(rgb, seg, g["samples"], g["segments"])
+    acc, rays = gpu_ctx.render(p)
+    assert rays == meta["rays"]
+    assert np.allclose(acc, g["sum"], rtol=2e-4, atol=1e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["cornell", "cornell_extra", "random_field", "bvh_stress_500"])
+@pytest.mark.parametrize("accel", [api.RTX_ACCEL_LINEAR, api.RTX_ACCEL_BVH])
+def test_hit_records_match_golden(gpu_ctx, name, accel):
+    g = util.load_golden("hits_" + name)
+    scene = api.HostScene(name, 32, 32)
+    gpu_ctx.upload(scene, accel)
+    got = gpu_ctx.hit(g["origins"], g["directions"])
+    assert np.array_equal(got["hit"], g["hit"].astype(np.int32))
+    m = g["hit"] == 1
+    for field in ("t", "p", "n"):
+        assert np.array_equal(got[field][m], g[field][m]), field
+    kinds = scene.arrays()["mat_kind"]
+    assert np.array_equal(kinds[got["material"][m]].astype(np.int8), g["mat_kind"][m])
+
+
+def test_bvh_and_linear_scan_agree_at_scale(gpu_ctx):
+    """Size-independent property: the tree only prunes the scan, so both return the same
+    nearest hit for every ray of a large batch (tie rule included)."""
+    rng = np.random.default_rng(11)
+    scene = api.HostScene("bvh_stress_20000", 64, 64)
+    n = 200_000
+    o = rng.uniform(0, 100, (n, 3)).astype(np.float32)
+    o[:, 1] = rng.uniform(0.1, 25, n)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+    lin = gpu_ctx.hit(o, d)
+    gpu_ctx.upload(scene, api.RTX_ACCEL_BVH)
+    assert gpu_ctx.info().n_bvh_nodes > 1000
+    bvh = gpu_ctx.hit(o, d)
+    for field in ("hit", "prim", "t", "p", "n", "material"):
+        assert np.array_equal(lin[field], bvh[field]), field
+    assert lin["hit"].mean() > 0.3
+
+
+def test_fast_mode_converges_to_cpu_ground_truth(gpu_ctx):
+    """Default (fast) mode: same estimator, arithmetic free to fuse / approximate.  At equal
+    spp its error against a 4096-spp CPU ground truth must equal the CPU tracer's own."""
+    from oracle import restate
+
+    g = util.load_golden("ground_truth_cornell_160x90")
+    gt = np.clip(g["mean"], 0, 1)
+    w, h, spp = 160, 90, 256
+    scene = api.HostScene("cornell", w, h)
+    gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+    fast, rays_fast = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_FAST, seed=5))
+    cpu = restate.render(scene, w, h, 0, spp, seed=5, threads=8)
+    rmse_fast = np.sqrt(np.mean((np.clip(fast / spp, 0, 1) - gt) ** 2))
+    rmse_cpu = np.sqrt(np.mean((np.clip(cpu["sum"] / spp, 0, 1) - gt) ** 2))
+    assert rmse_fast < 1.05 * rmse_cpu + 1e-4, (rmse_fast, rmse_cpu)
+    assert abs(rays_fast / cpu["rays"] - 1) < 0.01
+    # unbiased: means agree far below the per-pixel noise
+    assert abs(np.clip(fast / spp, 0, 1).mean() - gt.mean()) < 0.003
+    assert not np.isnan(fast).any()
+
+
+def test_sample_ranges_and_accumulate_compose(gpu_ctx):
+    w, h = 80, 45
+    scene = api.HostScene("cornell_extra", w, h)
+    gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+    for mode in (api.RTX_MODE_DETERMINISTIC, api.RTX_MODE_FAST):
+        whole, r = gpu_ctx.render(gpu_ctx.params(w, h, 4, 6, mode=mode, seed=2))
+        a, ra = gpu_ctx.render(gpu_ctx.params(w, h, 4, 2, mode=mode, seed=2))
+        b, rb = gpu_ctx.render(gpu_ctx.params(w, h, 6, 4, mode=mode, seed=2))
+        assert r == ra + rb
+        assert np.allclose(whole, a + b, rtol=1e-5, atol=1e-6)
+        both, _ = gpu_ctx.render(gpu_ctx.params(w, h, 6, 4, mode=mode, seed=2, accumulate=True), a.copy())
+        assert np.allclose(both, a + b, rtol=1e-6, atol=1e-7)
+
+
+def test_edge_cases(gpu_ctx):
+    scene = api.HostScene("cornell", 17, 9)  # ragged: not a multiple of the 16x16 tile
+    gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+    acc, rays = gpu_ctx.render(gpu_ctx.params(17, 9, 0, 0))  # zero samples
+    assert rays == 0 and not acc.any()
+    acc, rays = gpu_ctx.render(gpu_ctx.params(17, 9, 0, 3, mode=api.RTX_MODE_DETERMINISTIC))
+    assert rays >= 17 * 9 * 3 and np.isfinite(acc).all()
+    acc1, rays1 = gpu_ctx.render(gpu_ctx.params(1, 1, 0, 5, mode=api.RTX_MODE_DETERMINISTIC))
+    assert rays1 >= 5
+    # depth cap 0: every path is exactly one segment (Scene.cpp:108)
+    acc0, rays0 = gpu_ctx.render(gpu_ctx.params(17, 9, 0, 4, mode=api.RTX_MODE_DETERMINISTIC, max_depth=0))
+    assert rays0 == 17 * 9 * 4
+    with pytest.raises(api.RtxError):
+        gpu_ctx.render(gpu_ctx.params(0, 9, 0, 1))
+    assert gpu_ctx.hit(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)).shape == (0,)
+
+
+def test_device_resolve_matches_host_filter_chain(gpu_ctx):
+    import torch
+
+    w, h, spp = 96, 54, 16
+    scene = api.HostScene("cornell", w, h)
+    gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+    acc = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    rays = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    s = torch.cuda.current_stream()
+    gpu_ctx.render_device(gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_DETERMINISTIC, seed=4), acc.data_ptr(),
+                          rays.data_ptr(), s.cuda_stream)
+    acc[0, 0, :] = float("nan")  # NaN filter -> magenta
+    got = gpu_ctx.resolve_device(w, h, spp, acc.data_ptr(), s.cuda_stream)
+    want = api.resolve_host(acc.cpu().numpy(), spp)
+    assert got[0, 0].tolist() == [255, 0, 255]
+    # device powf vs host powf: at most one 8-bit code apart
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    assert np.count_nonzero(got != want) < 0.01 * got.size
+    host_acc, host_rays = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_DETERMINISTIC, seed=4))
+    assert int(rays.item()) == host_rays
