@@ -114,6 +114,13 @@ def load_librtx() -> C.CDLL:
     """Load the HIP library.  Raises OSError if it has not been built."""
     global _librtx
     if _librtx is None:
+        # PyTorch wheels bundle their own HIP runtime (same SONAME as /opt/rocm's).  Two HIP
+        # runtimes in one process do not both see the GPU, so when torch is installed it must be
+        # loaded FIRST; librtx.so then binds to the runtime already in the process.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = librtx_path()
         if not os.path.exists(path):
             raise OSError(f"{path} is missing: build it with `make -C raytrace_amd/csrc` "

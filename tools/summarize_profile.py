@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 result databases written by tools/profile_bench.sh into one text
+summary (per-kernel timing from the --kernel-trace --stats run, per-kernel PMC sums from
+the --pmc runs, and the derived figures quoted in DESIGN.md).
+
+    python tools/summarize_profile.py gpurun_out/prof_<tag> > profiles/<name>.txt
+"""
+import glob
+import os
+import sqlite3
+import sys
+
+
+def rows(db, q):
+    con = sqlite3.connect(db)
+    try:
+        return list(con.execute(q))
+    finally:
+        con.close()
+
+
+def main():
+    root = sys.argv[1]
+    print(f"# rocprofv3 summary of {root}")
+    stats = glob.glob(os.path.join(root, "stats", "*.db"))
+    log = os.path.join(root, "stats.log")
+    if os.path.exists(log):
+        for line in open(log):
+            if line.startswith("{"):
+                print("\n## bench.py line of the profiled run (rocprofv3 --kernel-trace --stats)\n" + line.strip())
+    if stats:
+        print("\n## kernel trace stats (all dispatches of the run, warm-up included)")
+        print(f"{'kernel':90s} {'calls':>6s} {'total_us':>14s} {'avg_us':>12s} {'pct':>7s}")
+        for name, calls, total, avg, pct in rows(stats[0], "select name,total_calls,total_duration,average,percentage from top_kernels"):
+            print(f"{name[:90]:90s} {calls:6d} {total:14.1f} {avg:12.1f} {pct:7.2f}")
+        print("\n## per-dispatch durations of the path-trace kernel")
+        print(f"{'dispatch':>8s} {'duration_us':>12s} {'grid':>10s} {'wg':>5s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'lds':>6s} {'scratch':>8s}")
+        for r in rows(stats[0], "select dispatch_id, duration, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size "
+                                "from kernels where name like '%trace_kernel%' order by start"):
+            print(f"{r[0]:8d} {r[1] / 1e3:12.1f} {r[2]:10d} {r[3]:5d} {r[4]:5d} {r[5]:5d} {r[6]:5d} {r[7]:6d} {r[8]:8d}")
+    counters = {}
+    meta = None
+    for db in sorted(glob.glob(os.path.join(root, "pmc*", "*.db"))):
+        for kname, cname, n, total, vg, sg, lds in rows(db, "select kernel_name, counter_name, count(*), sum(value), max(vgpr_count), max(sgpr_count), max(lds_block_size) "
+                                                       "from counters_collection where kernel_name like '%trace_kernel%' group by kernel_name, counter_name"):
+            counters[cname] = (total / n, n, kname)
+            meta = (kname, vg, sg, lds)
+    if counters:
+        print(f"\n## PMC counters of {meta[0]} (average per dispatch; separate --pmc runs)")
+        print(f"   vgpr_count {meta[1]}  sgpr_count {meta[2]}  lds {meta[3]}")
+        for k in sorted(counters):
+            print(f"{k:28s} {counters[k][0]:22.1f}   (n={counters[k][1]})")
+        c = {k: v[0] for k, v in counters.items()}
+        print("\n## derived")
+        if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
+            print(f"VALU active-lane fraction  = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU) = {c['SQ_THREAD_CYCLES_VALU'] / (64 * c['SQ_ACTIVE_INST_VALU']):.3f}")
+        if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c:
+            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over SIMDs; SQ_BUSY_CYCLES per SE
+            pass
+        if "GRBM_GUI_ACTIVE" in c:
+            print(f"GRBM_GUI_ACTIVE / 8 XCDs   = {c['GRBM_GUI_ACTIVE'] / 8:.0f} cycles per dispatch")
+        if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+            cyc = c["GRBM_GUI_ACTIVE"] / 8
+            # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles; 1024 SIMDs
+            print(f"VALU issue-slot occupancy  = SQ_INSTS_VALU * 2 / (1024 SIMDs * cycles) = {c['SQ_INSTS_VALU'] * 2 / (1024 * cyc):.3f}")
+        if "SQ_WAVE_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+            cyc = c["GRBM_GUI_ACTIVE"] / 8
+            print(f"mean resident waves / SIMD = SQ_WAVE_CYCLES * 4 / (1024 SIMDs * cycles) = {c['SQ_WAVE_CYCLES'] * 4 / (1024 * cyc):.2f}   (SQ_WAVE_CYCLES counts quad-cycles)")
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if k in c and "SQ_WAVE_CYCLES" in c:
+                print(f"{k} / SQ_WAVE_CYCLES = {c[k] / c['SQ_WAVE_CYCLES']:.3f}")
+        if "FETCH_SIZE" in c:
+            print(f"HBM read  per dispatch     = FETCH_SIZE {c['FETCH_SIZE']:.1f} KiB (x2 gfx950 correction for wide reads not applied: scalar / dword traffic)")
+        if "WRITE_SIZE" in c:
+            print(f"HBM write per dispatch     = WRITE_SIZE {c['WRITE_SIZE']:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()
