@@ -63,6 +63,7 @@ struct RtxContext {
     rtxd::SceneView view{};
     RtxSceneInfo info{};
     DeviceArray<rtxd::Prim> prims;
+    DeviceArray<rtxd::PrimInfo> prim_info;
     DeviceArray<rtxd::Group> groups;
     DeviceArray<rtxd::Step> steps;
     DeviceArray<rtxd::Material> materials;
@@ -220,9 +221,9 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     for (uint32_t p = 0; p < s->n_prims; ++p) {
         rtxd::Prim& P = prims[p];
         P.a = s->prim_a[p]; P.b = s->prim_b[p]; P.c = s->prim_c[p]; P.d = s->prim_d[p]; P.e = s->prim_e[p];
-        P.kind = s->prim_kind[p];
-        P.flip = s->prim_flip[p] ? 1u : 0u;
+        P.kind_flip = s->prim_kind[p] | (s->prim_flip[p] ? 4u : 0u);
         P.material = s->prim_material[p];
+        P.group = 0;
     }
     std::vector<rtxd::Step> steps(s->n_steps);
     for (uint32_t k = 0; k < s->n_steps; ++k) {
@@ -240,6 +241,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
         uint32_t q = p + 1;
         if (!(use_bvh && c == 0))
             while (q < s->n_prims && s->prim_chain[q] == c) ++q;
+        for (uint32_t k = p; k < q; ++k) prims[k].group = (uint32_t)groups.size();
         groups.push_back(rtxd::Group{p, q, s->chain_begin[c], s->chain_begin[c + 1]});
         p = q;
     }
@@ -261,6 +263,32 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
         E.kind = s->light_kind[l];
         E.pad[0] = E.pad[1] = 0;
     }
+    // one record per primitive with all the integrator needs after a hit
+    std::vector<rtxd::PrimInfo> info(s->n_prims);
+    for (uint32_t p = 0; p < s->n_prims; ++p) {
+        rtxd::PrimInfo& I = info[p];
+        const uint32_t m = s->prim_material[p];
+        const uint32_t mk = s->mat_kind[m];
+        I.param = s->mat_param[m];
+        I.bits = s->prim_kind[p] | (s->prim_flip[p] ? rtxd::kInfoFlip : 0u) | (mk << rtxd::kInfoMatShift);
+        I.texture = 0;
+        I.r = I.g = I.b = 1.0f;
+        if (mk != RTX_MAT_DIELECTRIC) {
+            const uint32_t t = s->mat_texture[m];
+            I.texture = t;
+            if (s->tex_kind[t] == RTX_TEX_COLOR) {
+                I.r = s->tex_r[t]; I.g = s->tex_g[t]; I.b = s->tex_b[t];
+            } else {
+                I.bits |= rtxd::kInfoTextured;
+            }
+        }
+        const uint32_t c = s->prim_chain[p];
+        I.step_begin = s->chain_begin[c];
+        I.step_end = s->chain_begin[c + 1];
+    }
+    // the scan requests record p+1 while it tests record p: keep one readable pad record
+    std::vector<rtxd::Prim> prims_padded = prims;
+    prims_padded.push_back(prims.back());
     std::vector<rtxd::BvhNode> nodes;
     std::vector<uint32_t> items;
     if (use_bvh) {
@@ -268,7 +296,8 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
         if (!rtxbvh::build(prims, groups, steps, nodes, items, err)) return fail(RTX_ERR_TOO_LARGE, err);
     }
 
-    RTX_HIP(ctx->prims.upload(prims));
+    RTX_HIP(ctx->prims.upload(prims_padded));
+    RTX_HIP(ctx->prim_info.upload(info));
     RTX_HIP(ctx->groups.upload(groups));
     RTX_HIP(ctx->steps.upload(steps));
     RTX_HIP(ctx->materials.upload(mats));
@@ -279,6 +308,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
 
     rtxd::SceneView& v = ctx->view;
     v.prims = ctx->prims.ptr;
+    v.info = ctx->prim_info.ptr;
     v.groups = ctx->groups.ptr;
     v.steps = ctx->steps.ptr;
     v.materials = ctx->materials.ptr;

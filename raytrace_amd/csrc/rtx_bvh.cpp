@@ -47,7 +47,8 @@ void quat_rotate(const rtxd::Step& q, double v[3]) {
 
 Box prim_box(const rtxd::Prim& P) {
     Box b;
-    if (P.kind == RTX_PRIM_SPHERE) {
+    const uint32_t kind = P.kind_flip & 3u;
+    if (kind == RTX_PRIM_SPHERE) {
         double r = std::fabs((double)P.d);
         double lo[3] = {P.a - r, P.b - r, P.c - r}, hi[3] = {P.a + r, P.b + r, P.c + r};
         b.add(lo);
@@ -55,8 +56,8 @@ Box prim_box(const rtxd::Prim& P) {
         return b;
     }
     int xi, yi, zi;
-    if (P.kind == RTX_PRIM_RECT_XY) { xi = 0; yi = 1; zi = 2; }
-    else if (P.kind == RTX_PRIM_RECT_XZ) { xi = 0; yi = 2; zi = 1; }
+    if (kind == RTX_PRIM_RECT_XY) { xi = 0; yi = 1; zi = 2; }
+    else if (kind == RTX_PRIM_RECT_XZ) { xi = 0; yi = 2; zi = 1; }
     else { xi = 1; yi = 2; zi = 0; }
     double lo[3], hi[3];
     lo[xi] = std::min(P.a, P.b); hi[xi] = std::max(P.a, P.b);

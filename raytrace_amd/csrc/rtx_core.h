@@ -98,7 +98,6 @@ RTX_DEV V3 normalize(V3 a) {  // vec_aos.h:474-485: v * (1 / sqrt(len2))
 RTX_DEV V3 cross(V3 a, V3 b) {  // vec_aos.h:487-494
     return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-RTX_DEV float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
 // rotate(quat, vec), quat_aos.h:400-412
 RTX_DEV V3 qrotate(float qx, float qy, float qz, float qw, V3 v) {
@@ -115,43 +114,73 @@ RTX_DEV V3 qrotate(float qx, float qy, float qz, float qw, V3 v) {
 // compiler (scalar loads, SGPR operands).
 template <typename T>
 RTX_DEV T load_uniform(const T* base, uint32_t i) {
-    return base[__builtin_amdgcn_readfirstlane(i)];
+    return base[(uint32_t)__builtin_amdgcn_readfirstlane(i)];
 }
 
 struct HitRec {
     float t;
     V3 p, n;
     uint32_t prim;
-    uint32_t material;
+    // material of the winning primitive (PrimInfo)
+    uint32_t bits;     // kInfo*
+    uint32_t texture;
+    float param;
+    V3 color;
 };
+RTX_DEV uint32_t rec_mat_kind(const HitRec& r) { return (r.bits >> kInfoMatShift) & 3u; }
 
 // ---------------------------------------------------------------------------
 // primitive tests.  Both return the accepted t or leave `t_out` untouched.
 // ---------------------------------------------------------------------------
+template <int I>
+RTX_DEV float comp(V3 a) { return I == 0 ? a.x : (I == 1 ? a.y : a.z); }
 
-// Rect::hit, Rect.cpp:16-25.  A NaN t or NaN x / y passes both rejection tests,
-// exactly as in the reference (the comparisons are written as rejections).
-RTX_DEV bool rect_test(const Prim& P, V3 o, V3 d, V3 inv_d, float t0, float t1, float& t_out) {
-    int xi, yi, zi;
-    if (P.kind == RTX_PRIM_RECT_XY) { xi = 0; yi = 1; zi = 2; }
-    else if (P.kind == RTX_PRIM_RECT_XZ) { xi = 0; yi = 2; zi = 1; }
-    else { xi = 1; yi = 2; zi = 0; }
+// Per-ray constants of one group's frame (fast mode only; empty in deterministic mode).
+struct RayAux {
+#if !RTX_DET
+    V3 inv_d;  // 1 / d
+    V3 noi;    // -o / d, so that (k - o) / d = k * inv_d + noi is one fma
+#endif
+};
+RTX_DEV RayAux make_aux(V3 o, V3 d) {
+    RayAux a;
+#if !RTX_DET
+    a.inv_d = v3(frcp(d.x), frcp(d.y), frcp(d.z));
+    a.noi = v3(-o.x * a.inv_d.x, -o.y * a.inv_d.y, -o.z * a.inv_d.z);
+#endif
+    return a;
+}
+
+// Rect::hit, Rect.cpp:16-25, for one axis type (XI, YI in-plane, ZI normal).  In
+// deterministic mode a NaN t or NaN x / y passes both rejection tests exactly as in the
+// reference (the comparisons are written as rejections).
+template <int XI, int YI, int ZI>
+RTX_DEV bool rect_axis(float x0, float x1, float y0, float y1, float k, V3 o, V3 d, const RayAux& aux,
+                       float t0, float t1, float& t_out) {
 #if RTX_DET
-    float t = (P.e - comp(o, zi)) / comp(d, zi);
-    (void)inv_d;
+    float t = (k - comp<ZI>(o)) / comp<ZI>(d);
     if (t < t0 || t > t1) return false;
-    float x = comp(o, xi) + t * comp(d, xi);
-    float y = comp(o, yi) + t * comp(d, yi);
-    if (x < P.a || x > P.b || y < P.c || y > P.d) return false;
+    float x = comp<XI>(o) + t * comp<XI>(d);
+    float y = comp<YI>(o) + t * comp<YI>(d);
+    if (x < x0 || x > x1 || y < y0 || y > y1) return false;
 #else
-    float t = (P.e - comp(o, zi)) * comp(inv_d, zi);
-    float x = comp(o, xi) + t * comp(d, xi);
-    float y = comp(o, yi) + t * comp(d, yi);
-    bool ok = (t >= t0) & (t <= t1) & (x >= P.a) & (x <= P.b) & (y >= P.c) & (y <= P.d);
+    float t = __builtin_fmaf(k, comp<ZI>(aux.inv_d), comp<ZI>(aux.noi));
+    float x = __builtin_fmaf(t, comp<XI>(d), comp<XI>(o));
+    float y = __builtin_fmaf(t, comp<YI>(d), comp<YI>(o));
+    bool ok = (t >= t0) & (t <= t1) & (x >= x0) & (x <= x1) & (y >= y0) & (y <= y1);
     if (!ok) return false;
 #endif
     t_out = t;
     return true;
+}
+
+// Rect::hit with the axis type taken from the record.  `kind` is wave-uniform on the
+// linear-scan path, so the switch is a scalar branch.
+RTX_DEV bool rect_test(uint32_t kind, float x0, float x1, float y0, float y1, float k, V3 o, V3 d,
+                       const RayAux& aux, float t0, float t1, float& t_out) {
+    if (kind == RTX_PRIM_RECT_XY) return rect_axis<0, 1, 2>(x0, x1, y0, y1, k, o, d, aux, t0, t1, t_out);
+    if (kind == RTX_PRIM_RECT_XZ) return rect_axis<0, 2, 1>(x0, x1, y0, y1, k, o, d, aux, t0, t1, t_out);
+    return rect_axis<1, 2, 0>(x0, x1, y0, y1, k, o, d, aux, t0, t1, t_out);
 }
 
 // Sphere::hit, Sphere.cpp:8-33 (roots only; p / n are derived by the caller).
@@ -162,90 +191,51 @@ RTX_DEV bool sphere_test(float cx, float cy, float cz, float radius, V3 o, V3 d,
     float b = 2.0f * dot(oc, d);
     float c = dot(oc, oc) - radius * radius;
     float D = b * b - (4.0f * a) * c;
+#if RTX_DET
     if (D > 0.0f) {
         float root = fsqrt(D);
-#if RTX_DET
         float temp = (-b - root) / (2.0f * a);
         if (temp < t1 && temp > t0) { t_out = temp; return true; }
         temp = (-b + root) / (2.0f * a);
         if (temp < t1 && temp > t0) { t_out = temp; return true; }
-#else
-        float inv2a = frcp(2.0f * a);
-        float ta = (-b - root) * inv2a;
-        float tb = (-b + root) * inv2a;
-        bool oka = (ta < t1) & (ta > t0);
-        bool okb = (tb < t1) & (tb > t0);
-        if (oka | okb) { t_out = oka ? ta : tb; return true; }
-#endif
     }
     return false;
-}
-
-// ---------------------------------------------------------------------------
-// nearest hit: linear scan in list order (ShapeList::hit, ShapeList.cpp:5-17)
-// ---------------------------------------------------------------------------
-
-// Finish the record of the winning primitive of one group in the group's local
-// frame, then carry it out through the group's wrappers (innermost first):
-// Rotate::hit (Rotate.cpp:12-13) rotates p and n, Translate::hit
-// (Translate.cpp:9) offsets p, FlipNormals::hit (FlipNormals.cpp:8) negates n.
-RTX_DEV void finish_hit(const SceneView& sc, const Group& G, uint32_t prim, float t, V3 ro, V3 rd,
-                        HitRec& rec) {
-    const Prim W = sc.prims[prim];  // per-lane
-    V3 p = ro + rd * t;             // Ray::at, Ray.h:12
-    V3 n;
-    if (W.kind == RTX_PRIM_SPHERE) {
-        n = vdivs(p - v3(W.a, W.b, W.c), W.d);  // Sphere.cpp:19
-    } else if (W.kind == RTX_PRIM_RECT_XY) {
-        n = v3(0.0f, 0.0f, 1.0f);
-    } else if (W.kind == RTX_PRIM_RECT_XZ) {
-        n = v3(0.0f, 1.0f, 0.0f);
-    } else {
-        n = v3(1.0f, 0.0f, 0.0f);
-    }
-    if (W.flip) n = -n;
-    for (uint32_t s = G.step_end; s > G.step_begin; --s) {
-        const Step S = load_uniform(sc.steps, s - 1);
-        if (S.kind == RTX_STEP_ROTATE) {
-            p = qrotate(S.x, S.y, S.z, S.w, p);
-            n = qrotate(S.x, S.y, S.z, S.w, n);
-        } else {
-            p = p + v3(S.x, S.y, S.z);
-        }
-    }
-    rec.t = t;
-    rec.p = p;
-    rec.n = n;
-    rec.prim = prim;
-    rec.material = W.material;
-}
-
-// Scan the primitives of one group with the ray already in the group's frame.
-RTX_DEV void scan_group(const SceneView& sc, const Group& G, V3 ro, V3 rd, float t0, float& closest,
-                        uint32_t& best) {
-    V3 inv_d = v3(0.0f, 0.0f, 0.0f);
-#if !RTX_DET
-    inv_d = v3(frcp(rd.x), frcp(rd.y), frcp(rd.z));
+#else
+    // branch-free: a negative discriminant makes the roots NaN and every comparison false
+    float root = fsqrt(D);
+    float inv2a = frcp(2.0f * a);
+    float ta = (-b - root) * inv2a;
+    float tb = (-b + root) * inv2a;
+    bool oka = (D > 0.0f) & (ta < t1) & (ta > t0);
+    bool okb = (D > 0.0f) & (tb < t1) & (tb > t0);
+    if (!(oka | okb)) return false;
+    t_out = oka ? ta : tb;
+    return true;
 #endif
-    for (uint32_t p = G.prim_begin; p < G.prim_end; ++p) {
-        const Prim P = load_uniform(sc.prims, p);
-        float t;
-        bool ok;
-        if (P.kind == RTX_PRIM_SPHERE) ok = sphere_test(P.a, P.b, P.c, P.d, ro, rd, t0, closest, t);
-        else ok = rect_test(P, ro, rd, inv_d, t0, closest, t);
-        if (ok) {
-            closest = t;
-            best = p;
-        }
-    }
 }
 
-// Bring a ray into a group's frame: Translate::hit (Translate.cpp:7) subtracts
-// the offset from the origin, Rotate::hit (Rotate.cpp:7-9) rotates origin and
-// direction by the conjugate quaternion; outermost wrapper first.
-RTX_DEV void enter_group(const SceneView& sc, const Group& G, V3& ro, V3& rd) {
-    for (uint32_t s = G.step_begin; s < G.step_end; ++s) {
-        const Step S = load_uniform(sc.steps, s);
+RTX_DEV uint32_t prim_kind(const Prim& P) { return P.kind_flip & 3u; }
+RTX_DEV bool prim_flip(const Prim& P) { return (P.kind_flip & 4u) != 0u; }
+
+// One primitive against a ray that is already in the primitive's frame.
+RTX_DEV bool prim_test(const Prim& P, V3 o, V3 d, const RayAux& aux, float t0, float t1, float& t) {
+    const uint32_t kind = prim_kind(P);
+    if (kind == RTX_PRIM_SPHERE) return sphere_test(P.a, P.b, P.c, P.d, o, d, t0, t1, t);
+    return rect_test(kind, P.a, P.b, P.c, P.d, P.e, o, d, aux, t0, t1, t);
+}
+
+// ---------------------------------------------------------------------------
+// transform chains
+// ---------------------------------------------------------------------------
+
+// Bring a ray into a group's frame: Translate::hit (Translate.cpp:7) subtracts the offset
+// from the origin, Rotate::hit (Rotate.cpp:7-9) rotates origin and direction by the
+// conjugate quaternion; outermost wrapper first.  kUniform: the group is the same in every
+// lane (scalar loads).
+template <bool kUniform>
+RTX_DEV void enter_group(const SceneView& sc, uint32_t step_begin, uint32_t step_end, V3& ro, V3& rd) {
+    for (uint32_t s = step_begin; s < step_end; ++s) {
+        const Step S = kUniform ? load_uniform(sc.steps, s) : sc.steps[s];
         if (S.kind == RTX_STEP_ROTATE) {
             ro = qrotate(-S.x, -S.y, -S.z, S.w, ro);
             rd = qrotate(-S.x, -S.y, -S.z, S.w, rd);
@@ -255,21 +245,96 @@ RTX_DEV void enter_group(const SceneView& sc, const Group& G, V3& ro, V3& rd) {
     }
 }
 
+// Complete the record of the winning primitive (per lane).  In the reference the record is
+// filled in the primitive's frame (Rect.cpp:27-32, Sphere.cpp:17-20) and carried out through
+// the wrappers innermost first: Rotate::hit (Rotate.cpp:12-13) rotates p and n,
+// Translate::hit (Translate.cpp:9) offsets p, FlipNormals::hit (FlipNormals.cpp:8) negates n.
+RTX_DEV void finish_hit(const SceneView& sc, uint32_t prim, float t, V3 o, V3 d, HitRec& rec) {
+    const PrimInfo I = sc.info[prim];  // two independent loads, one wait
+    const Prim W = sc.prims[prim];
+    const uint32_t kind = I.bits & kInfoKindMask;
+    const bool chained = I.step_end > I.step_begin;
+    V3 ro = o, rd = d;
+#if RTX_DET
+    if (chained) enter_group<false>(sc, I.step_begin, I.step_end, ro, rd);
+    V3 p = ro + rd * t;  // Ray::at, Ray.h:12
+    V3 pl = p;
+#else
+    // rotations and translations keep t, so the world-space point needs no way back; the
+    // local point is only needed for a sphere's normal
+    V3 p = o + d * t;
+    V3 pl = p;
+    if (chained && kind == RTX_PRIM_SPHERE) {
+        enter_group<false>(sc, I.step_begin, I.step_end, ro, rd);
+        pl = ro + rd * t;
+    }
+#endif
+    V3 n;
+    if (kind == RTX_PRIM_SPHERE) {
+#if RTX_DET
+        n = vdivs(pl - v3(W.a, W.b, W.c), W.d);  // Sphere.cpp:19
+#else
+        n = (pl - v3(W.a, W.b, W.c)) * frcp(W.d);
+#endif
+    } else {
+        n = v3(kind == RTX_PRIM_RECT_YZ ? 1.0f : 0.0f, kind == RTX_PRIM_RECT_XZ ? 1.0f : 0.0f,
+               kind == RTX_PRIM_RECT_XY ? 1.0f : 0.0f);
+    }
+    if (I.bits & kInfoFlip) n = -n;
+    if (chained) {
+        for (uint32_t s = I.step_end; s > I.step_begin; --s) {
+            const Step S = sc.steps[s - 1];
+            if (S.kind == RTX_STEP_ROTATE) {
+#if RTX_DET
+                p = qrotate(S.x, S.y, S.z, S.w, p);
+#endif
+                n = qrotate(S.x, S.y, S.z, S.w, n);
+            } else {
+#if RTX_DET
+                p = p + v3(S.x, S.y, S.z);
+#endif
+            }
+        }
+    }
+    rec.t = t;
+    rec.p = p;
+    rec.n = n;
+    rec.prim = prim;
+    rec.bits = I.bits;
+    rec.texture = I.texture;
+    rec.param = I.param;
+    rec.color = v3(I.r, I.g, I.b);
+}
+
+// ---------------------------------------------------------------------------
+// nearest hit: linear scan in list order (ShapeList::hit, ShapeList.cpp:5-17)
+// ---------------------------------------------------------------------------
+// Every lane of the wave walks the same groups and primitives, so the records are fetched
+// with scalar loads; the next record is requested before the current one is tested.  Only
+// (t, primitive) of the current winner is tracked during the scan; the record is completed
+// once, after the scan, for the final winner.
 RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec& rec) {
     float closest = t1;
-    bool any = false;
+    uint32_t best = kNone;
     for (uint32_t g = 0; g < sc.n_groups; ++g) {
         const Group G = load_uniform(sc.groups, g);
         V3 ro = o, rd = d;
-        enter_group(sc, G, ro, rd);
-        uint32_t best = kNone;
-        scan_group(sc, G, ro, rd, t0, closest, best);
-        if (best != kNone) {
-            finish_hit(sc, G, best, closest, ro, rd, rec);
-            any = true;
+        enter_group<true>(sc, G.step_begin, G.step_end, ro, rd);
+        const RayAux aux = make_aux(ro, rd);
+        Prim cur = load_uniform(sc.prims, G.prim_begin);
+        for (uint32_t p = G.prim_begin; p < G.prim_end; ++p) {
+            const Prim nxt = load_uniform(sc.prims, p + 1u);  // the array ends with a pad record
+            float t;
+            if (prim_test(cur, ro, rd, aux, t0, closest, t)) {
+                closest = t;
+                best = p;
+            }
+            cur = nxt;
         }
     }
-    return any;
+    if (best == kNone) return false;
+    finish_hit(sc, best, closest, o, d, rec);
+    return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -294,9 +359,8 @@ RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec
     uint32_t stack[kBvhStack];
     int sp = 0;
     float closest = t1;
-    uint32_t best = kNone, best_group = 0;
+    uint32_t best = kNone;
     bool best_is_rect = false;
-    V3 best_ro = o, best_rd = d;
     V3 inv = v3(frcp(d.x), frcp(d.y), frcp(d.z));
     uint32_t node = 0;
     for (;;) {
@@ -318,41 +382,21 @@ RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec
                 uint32_t g = sc.bvh_items[N.left + k];
                 const Group G = sc.groups[g];
                 V3 ro = o, rd = d;
-                for (uint32_t s = G.step_begin; s < G.step_end; ++s) {
-                    const Step S = sc.steps[s];
-                    if (S.kind == RTX_STEP_ROTATE) {
-                        ro = qrotate(-S.x, -S.y, -S.z, S.w, ro);
-                        rd = qrotate(-S.x, -S.y, -S.z, S.w, rd);
-                    } else {
-                        ro = ro - v3(S.x, S.y, S.z);
-                    }
-                }
-                V3 inv_d = v3(0.0f, 0.0f, 0.0f);
-#if !RTX_DET
-                inv_d = v3(frcp(rd.x), frcp(rd.y), frcp(rd.z));
-#endif
+                enter_group<false>(sc, G.step_begin, G.step_end, ro, rd);
+                const RayAux aux = make_aux(ro, rd);
                 for (uint32_t p = G.prim_begin; p < G.prim_end; ++p) {
                     const Prim P = sc.prims[p];
                     float t;
-                    bool is_rect = P.kind != RTX_PRIM_SPHERE;
-                    bool ok;
-                    // candidate t of this primitive alone, window (t0, closest] inclusive
-                    // so that ties reach the explicit rule below
-                    if (is_rect) {
-                        ok = rect_test(P, ro, rd, inv_d, t0, closest, t);
-                    } else {
-                        ok = sphere_test(P.a, P.b, P.c, P.d, ro, rd, t0, t1, t) && t <= closest;
-                    }
+                    bool is_rect = prim_kind(P) != RTX_PRIM_SPHERE;
+                    // candidate t of this primitive alone; the window is inclusive at
+                    // `closest` so that ties reach the explicit rule below
+                    bool ok = prim_test(P, ro, rd, aux, t0, is_rect ? closest : t1, t) && t <= closest;
                     if (ok) {
-                        bool take = t < closest || best == kNone ||
-                                    tie_wins(p, is_rect, best, best_is_rect);
+                        bool take = t < closest || best == kNone || tie_wins(p, is_rect, best, best_is_rect);
                         if (take) {
                             closest = t;
                             best = p;
                             best_is_rect = is_rect;
-                            best_group = g;
-                            best_ro = ro;
-                            best_rd = rd;
                         }
                     }
                 }
@@ -362,30 +406,7 @@ RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec
         node = stack[--sp];
     }
     if (best == kNone) return false;
-    const Group G = sc.groups[best_group];
-    // finish_hit() expects wave-uniform steps; do the per-lane equivalent here
-    const Prim W = sc.prims[best];
-    V3 p = best_ro + best_rd * closest;
-    V3 n;
-    if (W.kind == RTX_PRIM_SPHERE) n = vdivs(p - v3(W.a, W.b, W.c), W.d);
-    else if (W.kind == RTX_PRIM_RECT_XY) n = v3(0.0f, 0.0f, 1.0f);
-    else if (W.kind == RTX_PRIM_RECT_XZ) n = v3(0.0f, 1.0f, 0.0f);
-    else n = v3(1.0f, 0.0f, 0.0f);
-    if (W.flip) n = -n;
-    for (uint32_t s = G.step_end; s > G.step_begin; --s) {
-        const Step S = sc.steps[s - 1];
-        if (S.kind == RTX_STEP_ROTATE) {
-            p = qrotate(S.x, S.y, S.z, S.w, p);
-            n = qrotate(S.x, S.y, S.z, S.w, n);
-        } else {
-            p = p + v3(S.x, S.y, S.z);
-        }
-    }
-    rec.t = closest;
-    rec.p = p;
-    rec.n = n;
-    rec.prim = best;
-    rec.material = W.material;
+    finish_hit(sc, best, closest, o, d, rec);
     return true;
 }
 
@@ -406,6 +427,12 @@ RTX_DEV V3 texture_value(const SceneView& sc, uint32_t tex, V3 p) {
         tex = sines < 0.0f ? T.odd : T.even;
     }
     return v3(0.0f, 0.0f, 0.0f);
+}
+
+// Texture::value of the hit's material texture: plain colours come with the hit record.
+RTX_DEV V3 surface_color(const SceneView& sc, const HitRec& rec) {
+    if (rec.bits & kInfoTextured) return texture_value(sc, rec.texture, rec.p);
+    return rec.color;
 }
 
 // ---------------------------------------------------------------------------
@@ -472,12 +499,9 @@ RTX_DEV V3 light_random(const SceneView& sc, V3 o, RtxRng& rng) {
 // Shape::pdf_value of one light entry (Rect.cpp:36-48, Sphere.cpp:38-50, Shape.h:8)
 RTX_DEV float light_pdf_one(const Light& E, V3 o, V3 v) {
     if (E.kind == RTX_LIGHT_RECT_XZ) {
-        Prim P;
-        P.a = E.a; P.b = E.b; P.c = E.c; P.d = E.d; P.e = E.e;
-        P.kind = RTX_PRIM_RECT_XZ;
         float t;
-        V3 inv = v3(frcp(v.x), frcp(v.y), frcp(v.z));
-        if (!rect_test(P, o, v, inv, kTMin, kFltMax, t)) return 0.0f;
+        const RayAux aux = make_aux(o, v);
+        if (!rect_axis<0, 2, 1>(E.a, E.b, E.c, E.d, E.e, o, v, aux, kTMin, kFltMax, t)) return 0.0f;
         float area = (E.b - E.a) * (E.d - E.c);
         float distance_squared = (t * t) * length_sqr(v);
         float cosine = fdiv(__builtin_fabsf(v.y), length(v));  // |dot(v, (0,1,0))| / |v|
@@ -552,10 +576,10 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
         L = vmul(ps.T, v3(sc.background));
         return true;
     }
-    const Material M = sc.materials[rec.material];
-    if (M.kind == RTX_MAT_DIFFUSE_LIGHT) {  // DiffuseLight.h:17-28: emits on the front face, never scatters
+    const uint32_t mat_kind = rec_mat_kind(rec);
+    if (mat_kind == RTX_MAT_DIFFUSE_LIGHT) {  // DiffuseLight.h:17-28: emits on the front face, never scatters
         V3 e = v3(0.0f, 0.0f, 0.0f);
-        if (dot(rec.n, ps.d) < 0.0f) e = texture_value(sc, M.texture, rec.p);
+        if (dot(rec.n, ps.d) < 0.0f) e = surface_color(sc, rec);
         L = vmul(ps.T, e);
         return true;
     }
@@ -563,8 +587,8 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
     L = v3(0.0f, 0.0f, 0.0f);
     if (ps.depth >= max_depth) return true;  // Scene.cpp:108
 
-    if (M.kind == RTX_MAT_LAMBERTIAN) {
-        V3 albedo = texture_value(sc, M.texture, rec.p);  // Lambertian.cpp:17
+    if (mat_kind == RTX_MAT_LAMBERTIAN) {
+        V3 albedo = surface_color(sc, rec);  // Lambertian.cpp:17
         // MixturePdf::generate, MixturePdf.h:15-22
         V3 dir;
         if (rtx_rng_nextf(&ps.rng) < 0.5f) {
@@ -595,7 +619,7 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
         ps.depth += 1;
         return false;
     }
-    if (M.kind == RTX_MAT_METAL) {  // Metal.cpp:9-17
+    if (mat_kind == RTX_MAT_METAL) {  // Metal.cpp:9-17
         V3 reflected = reflect(normalize(ps.d), rec.n);
         V3 q;
         do {  // random_in_unit_sphere, Util.h:32-38; runs even when fuzz == 0.
@@ -606,8 +630,8 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
             float rx = rtx_rng_nextf(&ps.rng);
             q = v3(rx, ry, rz) * 2.0f - v3(1.0f, 1.0f, 1.0f);
         } while (length_sqr(q) >= 1.0f);
-        reflected = reflected + q * M.param;
-        V3 albedo = texture_value(sc, M.texture, rec.p);
+        reflected = reflected + q * rec.param;
+        V3 albedo = surface_color(sc, rec);
         if (!(dot(reflected, rec.n) > 0.0f)) return true;
         ps.T = vmul(albedo, ps.T);  // Scene.cpp:110
         ps.o = rec.p;
@@ -617,7 +641,7 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
     }
     // Dielectric, Dielectric.cpp:7-45
     {
-        float ri = M.param;
+        float ri = rec.param;
         V3 reflected = reflect(ps.d, rec.n);
         V3 outward;
         float ni_over_nt, cosine;
@@ -647,90 +671,120 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
 // kernels
 // ---------------------------------------------------------------------------
 
-// Pixel owned by this lane: 8x8 tile per wave, 2x2 waves per 256-thread block.
-RTX_DEV void lane_pixel(uint32_t tiles_x, uint32_t& i, uint32_t& j) {
-    uint32_t lane = threadIdx.x & 63u;
-    uint32_t wave = threadIdx.x >> 6;
-    uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
-    i = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
-    j = by * 16u + (wave >> 1) * 8u + (lane >> 3);
-}
-
-// The loops of Scene::render (Scene.cpp:140-149) around the integrator.  Each lane
-// owns one pixel and walks its samples in order; a lane whose path has ended starts
-// its next sample at once, so lanes of a wave are at different samples / depths but
-// all execute the same nearest-hit query each iteration.
+// The loops of Scene::render (Scene.cpp:140-149) around the integrator.
+//
+// Work distribution.  A wave owns an 8x8 pixel tile (2x2 waves per 256-thread block) and the
+// pool of its (pixel, sample) items: item k is pixel slot k & 63 of the tile, sample
+// spp_begin + (k >> 6).  A lane whose path has ended draws the next item of the pool
+// (wave64 ballot + prefix count), so every lane runs the nearest-hit query each iteration
+// until the pool is empty, whatever the path lengths of the individual pixels.  A finished
+// sample is added to its pixel's sum in LDS (one fp32 add per channel); lane l writes pixel
+// slot l to HBM once, at the end.  Only this wave touches its slice of LDS, and the wave
+// executes in lockstep, so the order of the adds - and with it every bit of the result -
+// is reproducible from run to run.
 template <bool kBvh, bool kSamples>
 __global__ void __launch_bounds__(256) trace_kernel(const TraceArgs a) {
+    __shared__ float s_acc[4][3][64];
     const SceneView& sc = a.scene;
-    uint32_t i, j;
-    lane_pixel((a.width + 15u) / 16u, i, j);
-    if (i >= a.width || j >= a.height) return;
-    const uint32_t pixel = j * a.width + i;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tiles_x = (a.width + 15u) / 16u;
+    const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const uint32_t x0 = bx * 16u + (wave & 1u) * 8u;  // tile origin; rows counted from the bottom
+    const uint32_t y0 = by * 16u + (wave >> 1) * 8u;
+    if (x0 >= a.width || y0 >= a.height) return;  // wave-uniform
+    const uint32_t tw = min(8u, a.width - x0), th = min(8u, a.height - y0);
 
-    V3 acc = v3(0.0f, 0.0f, 0.0f);
-    uint32_t rays = 0;
-    uint32_t s = 0;  // samples started
-    uint32_t segs = 0;
+    s_acc[wave][0][lane] = 0.0f;
+    s_acc[wave][1][lane] = 0.0f;
+    s_acc[wave][2][lane] = 0.0f;
+
+    const uint32_t total = 64u * a.spp_count;  // items of this wave's pool
+    uint32_t next = 0;                         // wave-uniform pool cursor
+    uint32_t rays = 0, segs = 0, item = 0;
     bool active = false;
     PathState ps;
     ps.o = ps.d = ps.T = v3(0.0f, 0.0f, 0.0f);
     ps.depth = 0;
     ps.rng.state = 0;
     ps.rng.inc = 1;
-    const float fi = (float)i, fj = (float)j;
     const float fnx = (float)a.width, fny = (float)a.height;
 
     for (;;) {
-        if (!active) {
-            if (s >= a.spp_count) break;
-            rtx_rng_init(&ps.rng, pixel, a.spp_begin + s, a.seed);
-            float u = fdiv(fi + rtx_rng_nextf(&ps.rng), fnx);  // Scene.cpp:145-146
-            float v = fdiv(fj + rtx_rng_nextf(&ps.rng), fny);
-            // Camera::getRay, Camera.h:24-26
-            ps.o = v3(sc.cam_origin);
-            ps.d = ((v3(sc.cam_ll) + v3(sc.cam_u) * u) + v3(sc.cam_v) * v) - ps.o;
-            ps.T = v3(1.0f, 1.0f, 1.0f);
-            ps.depth = 0;
-            segs = 0;
-            active = true;
-            ++s;
-        }
-        HitRec rec;
-        bool hit = scene_hit<kBvh>(sc, ps.o, ps.d, kTMin, kFltMax, rec);
-        ++segs;
-        V3 L;
-        if (shade(sc, a.max_depth, hit, rec, ps, L)) {
-            acc = acc + L;  // Scene.cpp:148
-            rays += segs;
-            if (kSamples) {
-                size_t k = (size_t)pixel * a.spp_count + (s - 1);
-                a.sample_rgb[3 * k + 0] = L.x;
-                a.sample_rgb[3 * k + 1] = L.y;
-                a.sample_rgb[3 * k + 2] = L.z;
-                if (a.sample_segments) a.sample_segments[k] = segs;
+        const unsigned long long want = __ballot(!active);
+        if (want != 0ull && next < total) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+            const uint32_t mine = next + rank;
+            next += (uint32_t)__popcll(want);
+            if (!active && mine < total) {
+                const uint32_t slot = mine & 63u;
+                const uint32_t sx = slot & 7u, sy = slot >> 3;
+                if (sx < tw && sy < th) {
+                    item = mine;
+                    const uint32_t i = x0 + sx, j = y0 + sy;
+                    rtx_rng_init(&ps.rng, j * a.width + i, a.spp_begin + (mine >> 6), a.seed);
+                    float u = fdiv((float)i + rtx_rng_nextf(&ps.rng), fnx);  // Scene.cpp:145-146
+                    float v = fdiv((float)j + rtx_rng_nextf(&ps.rng), fny);
+                    // Camera::getRay, Camera.h:24-26
+                    ps.o = v3(sc.cam_origin);
+                    ps.d = ((v3(sc.cam_ll) + v3(sc.cam_u) * u) + v3(sc.cam_v) * v) - ps.o;
+                    ps.T = v3(1.0f, 1.0f, 1.0f);
+                    ps.depth = 0;
+                    segs = 0;
+                    active = true;
+                }
             }
-            active = false;
+        }
+        if (__ballot(active) == 0ull) {
+            if (next >= total) break;
+            continue;  // only slots outside the image were drawn (ragged edge tile)
+        }
+        if (active) {
+            HitRec rec;
+            bool hit = scene_hit<kBvh>(sc, ps.o, ps.d, kTMin, kFltMax, rec);
+            ++segs;
+            V3 L;
+            if (shade(sc, a.max_depth, hit, rec, ps, L)) {
+                const uint32_t slot = item & 63u;
+                atomicAdd(&s_acc[wave][0][slot], L.x);  // Scene.cpp:148
+                atomicAdd(&s_acc[wave][1][slot], L.y);
+                atomicAdd(&s_acc[wave][2][slot], L.z);
+                rays += segs;
+                if (kSamples) {
+                    const uint32_t i = x0 + (slot & 7u), j = y0 + (slot >> 3);
+                    size_t k = (size_t)(j * a.width + i) * a.spp_count + (item >> 6);
+                    a.sample_rgb[3 * k + 0] = L.x;
+                    a.sample_rgb[3 * k + 1] = L.y;
+                    a.sample_rgb[3 * k + 2] = L.z;
+                    if (a.sample_segments) a.sample_segments[k] = segs;
+                }
+                active = false;
+            }
         }
     }
 
-    if (a.accum) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t sx = lane & 7u, sy = lane >> 3;
+    if (a.accum && sx < tw && sy < th) {
+        const uint32_t i = x0 + sx, j = y0 + sy;
         float* out = a.accum + ((size_t)(a.height - 1u - j) * a.width + i) * 3u;  // Scene.cpp:151
+        const float r = s_acc[wave][0][lane], g = s_acc[wave][1][lane], b = s_acc[wave][2][lane];
         if (a.accumulate) {
-            out[0] += acc.x;
-            out[1] += acc.y;
-            out[2] += acc.z;
+            out[0] += r;
+            out[1] += g;
+            out[2] += b;
         } else {
-            out[0] = acc.x;
-            out[1] = acc.y;
-            out[2] = acc.z;
+            out[0] = r;
+            out[1] = g;
+            out[2] = b;
         }
     }
     if (a.rays) {
         // wave-level sum, one atomic per wave
         uint32_t r = rays;
         for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
-        if ((threadIdx.x & 63u) == 0u) atomicAdd(a.rays, (unsigned long long)r);
+        if (lane == 0u) atomicAdd(a.rays, (unsigned long long)r);
     }
 }
 
@@ -745,7 +799,6 @@ __global__ void __launch_bounds__(256) hit_kernel(const HitArgs a) {
     rec.t = 0.0f;
     rec.p = rec.n = v3(0.0f, 0.0f, 0.0f);
     rec.prim = kNone;
-    rec.material = kNone;
     bool hit = scene_hit<kBvh>(a.scene, o, d, a.t0, a.t1, rec);
     if (k < a.n) {
         RtxHit* out = reinterpret_cast<RtxHit*>(a.hits) + k;
@@ -758,7 +811,7 @@ __global__ void __launch_bounds__(256) hit_kernel(const HitArgs a) {
         out->n[0] = hit ? rec.n.x : 0.0f;
         out->n[1] = hit ? rec.n.y : 0.0f;
         out->n[2] = hit ? rec.n.z : 0.0f;
-        out->material = hit ? (int32_t)rec.material : -1;
+        out->material = hit ? (int32_t)a.scene.prims[rec.prim].material : -1;
     }
 }
 

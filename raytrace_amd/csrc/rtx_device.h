@@ -14,10 +14,26 @@ namespace rtxd {
 // (Sphere.h:19-20): a,b,c = centre, d = radius.
 struct alignas(32) Prim {
     float a, b, c, d, e;
-    uint32_t kind;      // RTX_PRIM_*
-    uint32_t flip;      // FlipNormals parity
-    uint32_t material;  // index into Material[]
+    uint32_t kind_flip;  // bits 0-1: RTX_PRIM_*; bit 2: FlipNormals parity
+    uint32_t material;   // index into Material[]
+    uint32_t group;      // index into Group[] (the transform chain this primitive sits under)
 };
+
+// Everything the integrator needs about the primitive that won a nearest-hit query, in one
+// record, so that completing the hit and shading it costs one per-lane load instead of a
+// chain of dependent ones (primitive -> group -> steps, primitive -> material -> texture).
+struct alignas(32) PrimInfo {
+    float r, g, b;        // albedo / emission when the material's texture is a plain colour
+    float param;          // Metal fuzz | Dielectric refractive index
+    uint32_t bits;        // see kInfo* below
+    uint32_t texture;     // texture index when kInfoTextured is set
+    uint32_t step_begin;  // transform chain of the primitive's group, outermost wrapper first
+    uint32_t step_end;
+};
+constexpr uint32_t kInfoKindMask = 3u;       // RTX_PRIM_*
+constexpr uint32_t kInfoFlip = 4u;           // FlipNormals parity
+constexpr uint32_t kInfoMatShift = 3u;       // RTX_MAT_* in bits 3-4
+constexpr uint32_t kInfoTextured = 32u;      // texture is not a plain colour: evaluate it
 
 // A run of consecutive primitives that share one transform chain.
 struct alignas(16) Group {
@@ -63,7 +79,8 @@ struct alignas(32) BvhNode {
 
 // A BVH item: one group (a bare primitive is a group of one with an empty chain).
 struct SceneView {
-    const Prim* prims;
+    const Prim* prims;      // n_prims + 1 records (one readable pad record at the end)
+    const PrimInfo* info;   // n_prims records
     const Group* groups;
     const Step* steps;
     const Material* materials;
