@@ -69,6 +69,10 @@ struct RtxContext {
     DeviceArray<rtxd::Material> materials;
     DeviceArray<rtxd::Texture> textures;
     DeviceArray<rtxd::Light> lights;
+    DeviceArray<rtxd::ScanGroup> scan_groups;
+    DeviceArray<rtxd::ScanRec> scan_recs;
+    DeviceArray<rtxd::PrimInfo> scan_info;
+    DeviceArray<uint32_t> scan_orig;
     DeviceArray<rtxd::BvhNode> bvh;
     DeviceArray<uint32_t> bvh_items;
     // scratch owned by the host-buffer entry points
@@ -136,6 +140,67 @@ int check_scene(const RtxScene* s) {
     if (!s->light_is_list && s->n_lights != 1)
         return fail(RTX_ERR_INVALID_ARGUMENT, "a bare (non-list) light shape must have exactly one entry");
     return RTX_OK;
+}
+
+// Compose a group's step chain (outermost wrapper first) into one world->group affine map.
+// Each step maps p to p - offset (Translate.cpp:7) or to conj(q) p (Rotate.cpp:7-9).
+void compose_chain(const std::vector<rtxd::Step>& steps, uint32_t begin, uint32_t end, float out[12]) {
+    double M[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, m[3] = {0, 0, 0};
+    for (uint32_t s = begin; s < end; ++s) {
+        const rtxd::Step& S = steps[s];
+        if (S.kind == RTX_STEP_TRANSLATE) {
+            m[0] -= S.x; m[1] -= S.y; m[2] -= S.z;
+            continue;
+        }
+        const double x = -S.x, y = -S.y, z = -S.z, w = S.w;  // conjugate
+        const double R[3][3] = {
+            {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+            {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+            {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+        double M2[3][3], m2[3];
+        for (int i = 0; i < 3; ++i) {
+            m2[i] = R[i][0] * m[0] + R[i][1] * m[1] + R[i][2] * m[2];
+            for (int j = 0; j < 3; ++j) M2[i][j] = R[i][0] * M[0][j] + R[i][1] * M[1][j] + R[i][2] * M[2][j];
+        }
+        std::memcpy(M, M2, sizeof M);
+        std::memcpy(m, m2, sizeof m);
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) out[3 * i + j] = (float)M[i][j];
+        out[9 + i] = (float)m[i];
+    }
+}
+
+void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::PrimInfo>& info,
+                      const std::vector<rtxd::Group>& groups, const std::vector<rtxd::Step>& steps,
+                      std::vector<rtxd::ScanGroup>& sg, std::vector<rtxd::ScanRec>& sr,
+                      std::vector<rtxd::PrimInfo>& si, std::vector<uint32_t>& so) {
+    for (uint32_t g = 0; g < groups.size(); ++g) {
+        const rtxd::Group& G = groups[g];
+        rtxd::ScanGroup S{};
+        compose_chain(steps, G.step_begin, G.step_end, S.m);
+        S.identity = G.step_end == G.step_begin ? 1u : 0u;
+        S.first = (uint32_t)sr.size();
+        uint32_t* counts[4] = {&S.n_xy, &S.n_xz, &S.n_yz, &S.n_sph};
+        for (uint32_t kind = 0; kind < 4; ++kind) {
+            for (uint32_t p = G.prim_begin; p < G.prim_end; ++p) {
+                const rtxd::Prim& P = prims[p];
+                if ((P.kind_flip & 3u) != kind) continue;
+                rtxd::ScanRec R{};
+                R.a = P.a; R.b = P.b; R.c = P.c; R.d = P.d;
+                R.e = kind == RTX_PRIM_SPHERE ? P.d * P.d : P.e;
+                sr.push_back(R);
+                rtxd::PrimInfo I = info[p];
+                I.step_begin = g;
+                I.step_end = S.identity ? g : g + 1u;
+                si.push_back(I);
+                so.push_back(p);
+                ++*counts[kind];
+            }
+        }
+        sg.push_back(S);
+    }
+    sr.push_back(sr.back());  // readable pad record
 }
 
 int check_params(const RtxContext* ctx, const RtxParams* p) {
@@ -289,6 +354,12 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     // the scan requests record p+1 while it tests record p: keep one readable pad record
     std::vector<rtxd::Prim> prims_padded = prims;
     prims_padded.push_back(prims.back());
+    // bucketed table for the fast-mode linear scan
+    std::vector<rtxd::ScanGroup> scan_groups;
+    std::vector<rtxd::ScanRec> scan_recs;
+    std::vector<rtxd::PrimInfo> scan_info;
+    std::vector<uint32_t> scan_orig;
+    if (!use_bvh) build_scan_table(prims, info, groups, steps, scan_groups, scan_recs, scan_info, scan_orig);
     std::vector<rtxd::BvhNode> nodes;
     std::vector<uint32_t> items;
     if (use_bvh) {
@@ -303,6 +374,10 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     RTX_HIP(ctx->materials.upload(mats));
     RTX_HIP(ctx->textures.upload(texs));
     RTX_HIP(ctx->lights.upload(lights));
+    RTX_HIP(ctx->scan_groups.upload(scan_groups));
+    RTX_HIP(ctx->scan_recs.upload(scan_recs));
+    RTX_HIP(ctx->scan_info.upload(scan_info));
+    RTX_HIP(ctx->scan_orig.upload(scan_orig));
     RTX_HIP(ctx->bvh.upload(nodes));
     RTX_HIP(ctx->bvh_items.upload(items));
 
@@ -314,6 +389,12 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     v.materials = ctx->materials.ptr;
     v.textures = ctx->textures.ptr;
     v.lights = ctx->lights.ptr;
+    v.scan_groups = use_bvh ? nullptr : ctx->scan_groups.ptr;
+    v.scan_recs = use_bvh ? nullptr : ctx->scan_recs.ptr;
+    v.scan_info = use_bvh ? nullptr : ctx->scan_info.ptr;
+    v.scan_orig = use_bvh ? nullptr : ctx->scan_orig.ptr;
+    v.n_scan_groups = (uint32_t)scan_groups.size();
+    v.scan_pad_ = 0;
     v.bvh = use_bvh ? ctx->bvh.ptr : nullptr;
     v.bvh_items = use_bvh ? ctx->bvh_items.ptr : nullptr;
     v.n_prims = s->n_prims;

@@ -310,9 +310,12 @@ RTX_DEV void finish_hit(const SceneView& sc, uint32_t prim, float t, V3 o, V3 d,
 // nearest hit: linear scan in list order (ShapeList::hit, ShapeList.cpp:5-17)
 // ---------------------------------------------------------------------------
 // Every lane of the wave walks the same groups and primitives, so the records are fetched
-// with scalar loads; the next record is requested before the current one is tested.  Only
-// (t, primitive) of the current winner is tracked during the scan; the record is completed
-// once, after the scan, for the final winner.
+// with scalar loads.  Only (t, primitive) of the current winner is tracked during the scan;
+// the record is completed once, after the scan, for the final winner.
+#if RTX_DET
+// Deterministic mode: list order, one generic loop (the order decides ties and the fate of
+// NaN candidates, both of which must come out as in the reference).  The next record is
+// requested before the current one is tested.
 RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec& rec) {
     float closest = t1;
     uint32_t best = kNone;
@@ -336,6 +339,109 @@ RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, Hit
     finish_hit(sc, best, closest, o, d, rec);
     return true;
 }
+RTX_DEV uint32_t original_prim(const SceneView&, uint32_t prim, bool) { return prim; }
+#else
+// Fast mode: the bucketed table (ScanGroup / ScanRec): per group one composed affine map and
+// four homogeneous loops (XY, XZ, YZ rects, spheres) whose bodies are branch-free.
+template <int XI, int YI, int ZI>
+RTX_DEV void scan_rects(const SceneView& sc, uint32_t& pos, uint32_t count, V3 ro, V3 rd, const RayAux& aux,
+                        float t0, float& closest, uint32_t& best) {
+    for (uint32_t k = 0; k < count; ++k, ++pos) {
+        const ScanRec R = load_uniform(sc.scan_recs, pos);
+        float t = __builtin_fmaf(R.e, comp<ZI>(aux.inv_d), comp<ZI>(aux.noi));
+        float x = __builtin_fmaf(t, comp<XI>(rd), comp<XI>(ro));
+        float y = __builtin_fmaf(t, comp<YI>(rd), comp<YI>(ro));
+        bool ok = (t >= t0) & (t <= closest) & (x >= R.a) & (x <= R.b) & (y >= R.c) & (y <= R.d);
+        closest = ok ? t : closest;
+        best = ok ? pos : best;
+    }
+}
+
+RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec& rec) {
+    float closest = t1;
+    uint32_t best = kNone;
+    for (uint32_t g = 0; g < sc.n_scan_groups; ++g) {
+        const ScanGroup G = load_uniform(sc.scan_groups, g);
+        V3 ro = o, rd = d;
+        if (!G.identity) {
+            ro = v3(G.m[0] * o.x + G.m[1] * o.y + G.m[2] * o.z + G.m[9],
+                    G.m[3] * o.x + G.m[4] * o.y + G.m[5] * o.z + G.m[10],
+                    G.m[6] * o.x + G.m[7] * o.y + G.m[8] * o.z + G.m[11]);
+            rd = v3(G.m[0] * d.x + G.m[1] * d.y + G.m[2] * d.z, G.m[3] * d.x + G.m[4] * d.y + G.m[5] * d.z,
+                    G.m[6] * d.x + G.m[7] * d.y + G.m[8] * d.z);
+        }
+        const RayAux aux = make_aux(ro, rd);
+        uint32_t pos = G.first;
+        scan_rects<0, 1, 2>(sc, pos, G.n_xy, ro, rd, aux, t0, closest, best);
+        scan_rects<0, 2, 1>(sc, pos, G.n_xz, ro, rd, aux, t0, closest, best);
+        scan_rects<1, 2, 0>(sc, pos, G.n_yz, ro, rd, aux, t0, closest, best);
+        if (G.n_sph) {
+            // roots of a t^2 + 2 h t + c = 0 with h = oc.d (Sphere.cpp:9-15 with b = 2h)
+            const float a = dot(rd, rd);
+            const float inv_a = frcp(a);
+            for (uint32_t k = 0; k < G.n_sph; ++k, ++pos) {
+                const ScanRec R = load_uniform(sc.scan_recs, pos);
+                V3 oc = ro - v3(R.a, R.b, R.c);
+                float h = dot(oc, rd);
+                float c = dot(oc, oc) - R.e;
+                float D = h * h - a * c;
+                float root = fsqrt(D);  // NaN for a negative discriminant: every test below fails
+                float ta = (-h - root) * inv_a;
+                float tb = (-h + root) * inv_a;
+                bool oka = (D > 0.0f) & (ta < closest) & (ta > t0);
+                bool okb = (D > 0.0f) & (tb < closest) & (tb > t0);
+                float t = oka ? ta : tb;
+                bool ok = oka | okb;
+                closest = ok ? t : closest;
+                best = ok ? pos : best;
+            }
+        }
+    }
+    if (best == kNone) return false;
+
+    // complete the record of the winner (per lane)
+    const PrimInfo I = sc.scan_info[best];
+    const ScanRec W = sc.scan_recs[best];
+    const uint32_t kind = I.bits & kInfoKindMask;
+    const bool chained = I.step_end != I.step_begin;
+    const V3 p = o + d * closest;
+    float m[9];
+    if (chained) {
+        const ScanGroup* G = sc.scan_groups + I.step_begin;
+        for (int k = 0; k < 9; ++k) m[k] = G->m[k];
+    }
+    V3 n;
+    if (kind == RTX_PRIM_SPHERE) {
+        V3 pl = p;
+        if (chained) {
+            const ScanGroup* G = sc.scan_groups + I.step_begin;
+            pl = v3(m[0] * p.x + m[1] * p.y + m[2] * p.z + G->m[9], m[3] * p.x + m[4] * p.y + m[5] * p.z + G->m[10],
+                    m[6] * p.x + m[7] * p.y + m[8] * p.z + G->m[11]);
+        }
+        n = (pl - v3(W.a, W.b, W.c)) * frcp(W.d);
+    } else {
+        n = v3(kind == RTX_PRIM_RECT_YZ ? 1.0f : 0.0f, kind == RTX_PRIM_RECT_XZ ? 1.0f : 0.0f,
+               kind == RTX_PRIM_RECT_XY ? 1.0f : 0.0f);
+    }
+    if (I.bits & kInfoFlip) n = -n;
+    if (chained)  // back to world space: the transpose of the world->group rotation
+        n = v3(m[0] * n.x + m[3] * n.y + m[6] * n.z, m[1] * n.x + m[4] * n.y + m[7] * n.z,
+               m[2] * n.x + m[5] * n.y + m[8] * n.z);
+    rec.t = closest;
+    rec.p = p;
+    rec.n = n;
+    rec.prim = best;
+    rec.bits = I.bits;
+    rec.texture = I.texture;
+    rec.param = I.param;
+    rec.color = v3(I.r, I.g, I.b);
+    return true;
+}
+// The fast linear scan reports positions of the bucketed table.
+RTX_DEV uint32_t original_prim(const SceneView& sc, uint32_t prim, bool bvh) {
+    return bvh ? prim : sc.scan_orig[prim];
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // nearest hit: BVH over groups, per-lane stack
@@ -803,7 +909,8 @@ __global__ void __launch_bounds__(256) hit_kernel(const HitArgs a) {
     if (k < a.n) {
         RtxHit* out = reinterpret_cast<RtxHit*>(a.hits) + k;
         out->hit = hit ? 1 : 0;
-        out->prim = hit ? (int32_t)rec.prim : -1;
+        const uint32_t prim = hit ? original_prim(a.scene, rec.prim, kBvh) : 0u;
+        out->prim = hit ? (int32_t)prim : -1;
         out->t = hit ? rec.t : 0.0f;
         out->p[0] = hit ? rec.p.x : 0.0f;
         out->p[1] = hit ? rec.p.y : 0.0f;
@@ -811,7 +918,7 @@ __global__ void __launch_bounds__(256) hit_kernel(const HitArgs a) {
         out->n[0] = hit ? rec.n.x : 0.0f;
         out->n[1] = hit ? rec.n.y : 0.0f;
         out->n[2] = hit ? rec.n.z : 0.0f;
-        out->material = hit ? (int32_t)a.scene.prims[rec.prim].material : -1;
+        out->material = hit ? (int32_t)a.scene.prims[prim].material : -1;
     }
 }
 

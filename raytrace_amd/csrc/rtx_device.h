@@ -35,6 +35,23 @@ constexpr uint32_t kInfoFlip = 4u;           // FlipNormals parity
 constexpr uint32_t kInfoMatShift = 3u;       // RTX_MAT_* in bits 3-4
 constexpr uint32_t kInfoTextured = 32u;      // texture is not a plain colour: evaluate it
 
+// Fast-mode linear scan: the primitives of a group re-ordered by kind (XY rects, XZ rects,
+// YZ rects, spheres) so that each kind is scanned by a branch-free loop over homogeneous
+// 32-byte records fetched with one scalar load each.
+struct alignas(32) ScanRec {
+    float a, b, c, d, e;  // rect: x0 x1 y0 y1 k | sphere: cx cy cz r r*r
+    uint32_t pad[3];
+};
+// One group of the bucketed table: the composed world->group affine map (rows of the 3x3
+// matrix then the offset) instead of the un-composed step chain, and the kind counts.
+struct alignas(16) ScanGroup {
+    float m[12];           // p_local = (m[0..2].p + m[9], m[3..5].p + m[10], m[6..8].p + m[11])
+    uint32_t first;        // index of the group's first ScanRec
+    uint32_t n_xy, n_xz, n_yz, n_sph;
+    uint32_t identity;     // 1: no transform
+    uint32_t pad[2];
+};
+
 // A run of consecutive primitives that share one transform chain.
 struct alignas(16) Group {
     uint32_t prim_begin, prim_end;
@@ -86,6 +103,13 @@ struct SceneView {
     const Material* materials;
     const Texture* textures;
     const Light* lights;
+    // bucketed copy for the fast-mode linear scan (null when a BVH is used)
+    const ScanGroup* scan_groups;
+    const ScanRec* scan_recs;      // n_prims + 1 records
+    const PrimInfo* scan_info;     // in scan order; step_begin = scan group, step_end = 1 if transformed
+    const uint32_t* scan_orig;     // scan position -> original primitive index
+    uint32_t n_scan_groups;
+    uint32_t scan_pad_;
     const BvhNode* bvh;        // null: linear scan over groups
     const uint32_t* bvh_items; // group index per BVH leaf slot
     uint32_t n_prims, n_groups, n_steps, n_materials, n_textures, n_lights, n_bvh_nodes;

@@ -229,3 +229,29 @@ def test_device_resolve_matches_host_filter_chain(gpu_ctx):
     assert np.count_nonzero(got != want) < 0.01 * got.size
     host_acc, host_rays = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_DETERMINISTIC, seed=4))
     assert int(rays.item()) == host_rays
+
+
+@pytest.mark.parametrize("name", ["cornell", "cornell_extra", "random_field", "bvh_stress_500"])
+@pytest.mark.parametrize("accel", [api.RTX_ACCEL_LINEAR, api.RTX_ACCEL_BVH])
+def test_fast_mode_hits_agree_with_golden_up_to_rounding(gpu_ctx, name, accel):
+    """Fast mode re-orders the scan and fuses / approximates arithmetic: the same primitive
+    must win except where two candidates are within rounding of each other."""
+    g = util.load_golden("hits_" + name)
+    scene = api.HostScene(name, 32, 32)
+    gpu_ctx.upload(scene, accel)
+    det = gpu_ctx.hit(g["origins"], g["directions"], mode=api.RTX_MODE_DETERMINISTIC)
+    fast = gpu_ctx.hit(g["origins"], g["directions"], mode=api.RTX_MODE_FAST)
+    same = (fast["hit"] == det["hit"]) & (fast["prim"] == det["prim"])
+    assert same.mean() > 0.995, same.mean()
+    m = same & (det["hit"] == 1)
+    # fp32 error of a hit point scales with the coordinates involved: the hit point itself or,
+    # for a sphere, its radius (the 1000-unit ground spheres cancel catastrophically in both modes)
+    a = scene.arrays()
+    big = float(np.max(a["prim_d"][a["prim_kind"] == 3], initial=1.0))
+    scale = np.maximum(np.abs(det["p"][m]).max(axis=1, keepdims=True), big)
+    assert (np.abs(fast["p"][m] - det["p"][m]) / scale).max() < 2e-4
+    dlen = np.linalg.norm(g["directions"][m], axis=1)
+    assert (np.abs(fast["t"][m] - det["t"][m]) * dlen / scale[:, 0]).max() < 2e-4
+    # a sphere normal is (p - c) / r: the hit point's rounding error divided by a radius of 0.05-0.2
+    assert np.abs(fast["n"][m] - det["n"][m]).max() < 5e-3
+    assert np.array_equal(fast["material"][m], det["material"][m])
