@@ -103,7 +103,8 @@ _libhost = None
 
 
 def librtx_path() -> str:
-    return os.path.join(_PKG_DIR, "librtx.so")
+    # RTX_LIBRTX selects another build of the same library (A/B timing of kernel variants)
+    return os.environ.get("RTX_LIBRTX") or os.path.join(_PKG_DIR, "librtx.so")
 
 
 def libhost_path() -> str:

@@ -32,6 +32,11 @@
 
 #define RTX_DEV __device__ __forceinline__
 
+// minimum resident waves per SIMD the trace kernel is compiled for (bounds its VGPR budget)
+#ifndef RTX_TRACE_WAVES
+#define RTX_TRACE_WAVES 4
+#endif
+
 namespace RTX_NS {
 
 using namespace rtxd;
@@ -526,7 +531,8 @@ RTX_DEV bool scene_hit(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitR
 // textures (Texture.h:5): ColorTexture.h:11-13, CheckerTexture.cpp:3-11
 // ---------------------------------------------------------------------------
 RTX_DEV V3 texture_value(const SceneView& sc, uint32_t tex, V3 p) {
-    for (int level = 0; level < 16; ++level) {
+#pragma unroll 1
+    for (int level = 0; level < 16; ++level) {  // nesting depth of CheckerTexture sub-textures
         const Texture T = sc.textures[tex];
         if (T.kind == RTX_TEX_COLOR) return v3(T.r, T.g, T.b);
         float sines = (fsin(T.r * p.x) * fsin(T.r * p.y)) * fsin(T.r * p.z);
@@ -563,43 +569,59 @@ RTX_DEV V3 onb_local(const Onb& b, V3 a) {  // ONB.h:24-26
 // light sampling: ShapeList / Rect / Sphere :: random and :: pdf_value
 // ---------------------------------------------------------------------------
 
-// Shape::random of one light entry (Rect.cpp:50-68, Sphere.cpp:52-58, Shape.h:9)
-RTX_DEV V3 light_random_one(const Light& E, V3 o, RtxRng& rng) {
-    if (E.kind == RTX_LIGHT_RECT_XZ) {
-        float x = E.a + rtx_rng_nextf(&rng) * (E.b - E.a);
-        float y = E.c + rtx_rng_nextf(&rng) * (E.d - E.c);
+// MixturePdf::generate (MixturePdf.h:15-22) for a diffuse hit: one draw picks between
+//   ShapePdf::generate -> Shape::random of the light shape (ShapePdf.h:15-17; for a list one
+//     more draw picks the entry, ShapeList.cpp:28-35; then Rect.cpp:50-68 or Sphere.cpp:52-58
+//     with random_to_sphere, Util.h:96-107; any other shape returns (1,0,0), Shape.h:9), and
+//   CosinePdf::generate (CosinePdf.cpp:16-20) with random_cosine_direction (Util.h:86-94).
+// The three samplers that draw (XZ rect, sphere, cosine) all consume exactly two more
+// numbers, and the sphere and cosine samplers share their shape: an orthonormal basis around
+// an axis, a polar angle from the second number, the azimuth 2*pi*r1 from the first.  They
+// are therefore evaluated by one code path; each lane still performs exactly the operations
+// of its own sampler, in the reference's order.
+constexpr uint32_t kSampleCosine = 5u;  // beyond the RTX_LIGHT_* kinds
+
+RTX_DEV V3 sample_direction(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
+    uint32_t kind = kSampleCosine;
+    Light E;
+    E.a = E.b = E.c = E.d = E.e = 0.0f;
+    if (rtx_rng_nextf(&rng) < 0.5f) {
+        uint32_t index = 0;
+        if (sc.light_is_list) {
+            float r = rtx_rng_nextf(&rng);
+            index = (uint32_t)(r * (float)sc.n_lights);
+            if (index >= sc.n_lights) index = sc.n_lights - 1;
+        }
+        E = sc.lights[index];  // per-lane
+        kind = E.kind;
+    }
+    const bool is_sphere = kind == RTX_LIGHT_SPHERE;
+    const bool is_rect = kind == RTX_LIGHT_RECT_XZ;
+    if (!(is_sphere | is_rect | (kind == kSampleCosine))) return v3(1.0f, 0.0f, 0.0f);
+    const float r1 = rtx_rng_nextf(&rng);
+    const float r2 = rtx_rng_nextf(&rng);
+    if (is_rect) {
+        float x = E.a + r1 * (E.b - E.a);
+        float y = E.c + r2 * (E.d - E.c);
         return v3(x, E.e, y) - o;
     }
-    if (E.kind == RTX_LIGHT_SPHERE) {
-        V3 direction = v3(E.a, E.b, E.c) - o;
-        float dd = length_sqr(direction);
-        Onb uvw = onb_from_w(direction);
-        // random_to_sphere, Util.h:96-107
-        float r1 = rtx_rng_nextf(&rng);
-        float r2 = rtx_rng_nextf(&rng);
+    const V3 axis = is_sphere ? v3(E.a, E.b, E.c) - o : n;
+    const Onb uvw = onb_from_w(axis);
+    float z, radial;
+    if (is_sphere) {
+        float dd = length_sqr(axis);
         float r2r = E.d * E.d;
         float rr = dd < r2r ? dd : r2r;  // std::min(pow2(radius), distance_squared)
         float cos_theta_max = fsqrt(1.0f - rr * frcp(dd));
-        float z = 1.0f - r2 * (1.0f - cos_theta_max);
-        float sqrtz = fsqrt(1.0f - z * z);
-        float sn, cs;
-        sincos_2pi(r1, sn, cs);
-        return onb_local(uvw, v3(cs * sqrtz, sn * sqrtz, z));
+        z = 1.0f - r2 * (1.0f - cos_theta_max);
+        radial = fsqrt(1.0f - z * z);
+    } else {
+        z = fsqrt(1.0f - r2);
+        radial = fsqrt(r2);
     }
-    return v3(1.0f, 0.0f, 0.0f);
-}
-
-// ShapePdf::generate -> Shape::random of the light shape (ShapePdf.h:15-17);
-// for a list one draw picks the entry (ShapeList.cpp:28-35).
-RTX_DEV V3 light_random(const SceneView& sc, V3 o, RtxRng& rng) {
-    uint32_t index = 0;
-    if (sc.light_is_list) {
-        float r = rtx_rng_nextf(&rng);
-        index = (uint32_t)(r * (float)sc.n_lights);
-        if (index >= sc.n_lights) index = sc.n_lights - 1;
-    }
-    const Light E = sc.lights[index];  // per-lane
-    return light_random_one(E, o, rng);
+    float sn, cs;
+    sincos_2pi(r1, sn, cs);
+    return onb_local(uvw, v3(cs * radial, sn * radial, z));
 }
 
 // Shape::pdf_value of one light entry (Rect.cpp:36-48, Sphere.cpp:38-50, Shape.h:8)
@@ -695,21 +717,7 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
 
     if (mat_kind == RTX_MAT_LAMBERTIAN) {
         V3 albedo = surface_color(sc, rec);  // Lambertian.cpp:17
-        // MixturePdf::generate, MixturePdf.h:15-22
-        V3 dir;
-        if (rtx_rng_nextf(&ps.rng) < 0.5f) {
-            dir = light_random(sc, rec.p, ps.rng);
-        } else {
-            // CosinePdf::generate (CosinePdf.cpp:16-20), random_cosine_direction (Util.h:86-94)
-            Onb uvw = onb_from_w(rec.n);
-            float r1 = rtx_rng_nextf(&ps.rng);
-            float r2 = rtx_rng_nextf(&ps.rng);
-            float z = fsqrt(1.0f - r2);
-            float sn, cs;
-            sincos_2pi(r1, sn, cs);
-            float sr2 = fsqrt(r2);
-            dir = onb_local(uvw, v3(cs * sr2, sn * sr2, z));
-        }
+        const V3 dir = sample_direction(sc, rec.p, rec.n, ps.rng);
         // MixturePdf::value, MixturePdf.h:9-13
         float pdf0 = light_pdf(sc, rec.p, dir);
         float cosine = dot(normalize(dir), rec.n);  // CosinePdf.cpp:7
@@ -789,7 +797,7 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
 // executes in lockstep, so the order of the adds - and with it every bit of the result -
 // is reproducible from run to run.
 template <bool kBvh, bool kSamples>
-__global__ void __launch_bounds__(256) trace_kernel(const TraceArgs a) {
+__global__ void __launch_bounds__(256, RTX_TRACE_WAVES) trace_kernel(const TraceArgs a) {
     __shared__ float s_acc[4][3][64];
     const SceneView& sc = a.scene;
     const uint32_t lane = threadIdx.x & 63u;
