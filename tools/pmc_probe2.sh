@@ -13,7 +13,7 @@ import sqlite3, glob
 c = {}
 for db in glob.glob("$OUT/p*/*.db"):
     con = sqlite3.connect(db)
-    for k, n, v in con.execute("select counter_name, count(*), sum(value) from counters_collection where kernel_name like '%trace_kernel%' group by counter_name"):
+    for k, n, v in con.execute("select counter_name, count(*), sum(value) from counters_collection where kernel_name like '%_mode::%' group by counter_name"):
         c[k] = v / n
 for k in sorted(c): print(f"{k:26s} {c[k]:20.0f}")
 PY

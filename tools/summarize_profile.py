@@ -36,13 +36,13 @@ def main():
         print("\n## per-dispatch durations of the path-trace kernel")
         print(f"{'dispatch':>8s} {'duration_us':>12s} {'grid':>10s} {'wg':>5s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'lds':>6s} {'scratch':>8s}")
         for r in rows(stats[0], "select dispatch_id, duration, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size "
-                                "from kernels where name like '%trace_kernel%' order by start"):
+                                "from kernels where name like '%_mode::%' order by start"):
             print(f"{r[0]:8d} {r[1] / 1e3:12.1f} {r[2]:10d} {r[3]:5d} {r[4]:5d} {r[5]:5d} {r[6]:5d} {r[7]:6d} {r[8]:8d}")
     counters = {}
     meta = None
     for db in sorted(glob.glob(os.path.join(root, "pmc*", "*.db"))):
         for kname, cname, n, total, vg, sg, lds in rows(db, "select kernel_name, counter_name, count(*), sum(value), max(vgpr_count), max(sgpr_count), max(lds_block_size) "
-                                                       "from counters_collection where kernel_name like '%trace_kernel%' group by kernel_name, counter_name"):
+                                                       "from counters_collection where kernel_name like '%_mode::%' group by kernel_name, counter_name"):
             counters[cname] = (total / n, n, kname)
             meta = (kname, vg, sg, lds)
     if counters:
