@@ -74,7 +74,7 @@ struct RtxContext {
     DeviceArray<rtxd::PrimInfo> scan_info;
     DeviceArray<uint32_t> scan_orig;
     DeviceArray<rtxd::BvhNode> bvh;
-    DeviceArray<uint32_t> bvh_items;
+    DeviceArray<rtxd::Group> bvh_items;
     // scratch owned by the host-buffer entry points
     DeviceArray<float> accum;
     DeviceArray<unsigned long long> rays;
@@ -361,7 +361,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     std::vector<uint32_t> scan_orig;
     if (!use_bvh) build_scan_table(prims, info, groups, steps, scan_groups, scan_recs, scan_info, scan_orig);
     std::vector<rtxd::BvhNode> nodes;
-    std::vector<uint32_t> items;
+    std::vector<rtxd::Group> items;
     if (use_bvh) {
         std::string err;
         if (!rtxbvh::build(prims, groups, steps, nodes, items, err)) return fail(RTX_ERR_TOO_LARGE, err);

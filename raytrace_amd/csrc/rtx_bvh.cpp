@@ -104,23 +104,28 @@ struct Task {
     int depth;
 };
 
-void write_node(rtxd::BvhNode& N, const Box& b, uint32_t left, uint32_t count) {
+// Intermediate one-box-per-node tree: inner nodes keep their children adjacent.
+struct TmpNode {
+    Box box;
+    uint32_t left = 0, count = 0;  // count == 0: inner, children left / left+1; else leaf items [left, left+count)
+};
+
+void store_box(float lo[3], float hi[3], const Box& b) {
     for (int a = 0; a < 3; ++a) {
         // round outwards when narrowing to fp32
-        N.lo[a] = std::nextafterf((float)b.lo[a], -FLT_MAX);
-        N.hi[a] = std::nextafterf((float)b.hi[a], FLT_MAX);
+        lo[a] = std::nextafterf((float)b.lo[a], -FLT_MAX);
+        hi[a] = std::nextafterf((float)b.hi[a], FLT_MAX);
     }
-    N.left = left;
-    N.count = count;
 }
 
 }  // namespace
 
 bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,
-           const std::vector<rtxd::Step>& steps, std::vector<rtxd::BvhNode>& nodes,
-           std::vector<uint32_t>& items, std::string& err) {
+           const std::vector<rtxd::Step>& steps, std::vector<rtxd::BvhNode>& out_nodes,
+           std::vector<rtxd::Group>& items, std::string& err) {
+    std::vector<TmpNode> nodes;
+    out_nodes.clear();
     const uint32_t n = (uint32_t)groups.size();
-    nodes.clear();
     items.clear();
     if (n == 0) {
         err = "no groups";
@@ -148,7 +153,9 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
         }
         const uint32_t count = t.end - t.begin;
         if (count <= kLeafItems) {
-            write_node(nodes[t.node], bounds, t.begin, count);
+            nodes[t.node].box = bounds;
+            nodes[t.node].left = t.begin;
+            nodes[t.node].count = count;
             continue;
         }
         if (t.depth >= kMaxDepth) {
@@ -220,12 +227,50 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
         const uint32_t left = (uint32_t)nodes.size();
         nodes.emplace_back();
         nodes.emplace_back();
-        write_node(nodes[t.node], bounds, left, 0);
+        nodes[t.node].box = bounds;
+        nodes[t.node].left = left;
+        nodes[t.node].count = 0;
         todo.push_back(Task{left, t.begin, mid, t.depth + 1});
         todo.push_back(Task{left + 1, mid, t.end, t.depth + 1});
     }
     items.resize(n);
-    for (uint32_t k = 0; k < n; ++k) items[k] = it[k].group;
+    for (uint32_t k = 0; k < n; ++k) items[k] = groups[it[k].group];
+
+    // Convert to two-child nodes.  A child reference is a node index or a tagged leaf.
+    std::vector<uint32_t> inner_index(nodes.size(), 0);
+    uint32_t n_inner = 0;
+    for (size_t k = 0; k < nodes.size(); ++k)
+        if (nodes[k].count == 0) inner_index[k] = n_inner++;
+    auto ref_of = [&](uint32_t k) -> uint32_t {
+        const TmpNode& N = nodes[k];
+        if (N.count == 0) return inner_index[k];
+        return rtxd::kBvhLeaf | (N.count << rtxd::kBvhLeafCountShift) | N.left;
+    };
+    if (n > rtxd::kBvhLeafFirst) {
+        err = "too many BVH items";
+        return false;
+    }
+    if (nodes[0].count != 0) {
+        // a single leaf: root node with one real child and one empty box
+        rtxd::BvhNode R{};
+        store_box(R.lo0, R.hi0, nodes[0].box);
+        for (int a = 0; a < 3; ++a) { R.lo1[a] = FLT_MAX; R.hi1[a] = -FLT_MAX; }
+        R.child0 = ref_of(0);
+        R.child1 = R.child0;
+        out_nodes.push_back(R);
+        return true;
+    }
+    out_nodes.resize(n_inner);
+    for (size_t k = 0; k < nodes.size(); ++k) {
+        const TmpNode& N = nodes[k];
+        if (N.count != 0) continue;
+        rtxd::BvhNode& O = out_nodes[inner_index[k]];
+        O = rtxd::BvhNode{};
+        store_box(O.lo0, O.hi0, nodes[N.left].box);
+        store_box(O.lo1, O.hi1, nodes[N.left + 1].box);
+        O.child0 = ref_of(N.left);
+        O.child1 = ref_of(N.left + 1);
+    }
     return true;
 }
 

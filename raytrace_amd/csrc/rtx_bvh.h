@@ -17,11 +17,10 @@ namespace rtxbvh {
 // Maximum tree depth the traversal stack supports (see kBvhStack in rtx_core.h).
 constexpr int kMaxDepth = 30;
 
-// nodes[0] is the root; inner nodes keep their children adjacent (left, left+1);
-// a leaf covers items[left .. left+count).  Returns false (and sets err) if the
-// tree cannot be built within kMaxDepth.
+// nodes[0] is the root (two-child nodes, see rtxd::BvhNode); `items` are the groups in leaf
+// order.  Returns false (and sets err) if the tree cannot be built within kMaxDepth.
 bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,
            const std::vector<rtxd::Step>& steps, std::vector<rtxd::BvhNode>& nodes,
-           std::vector<uint32_t>& items, std::string& err);
+           std::vector<rtxd::Group>& items, std::string& err);
 
 }  // namespace rtxbvh

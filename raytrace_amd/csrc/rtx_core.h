@@ -458,7 +458,7 @@ RTX_DEV uint32_t original_prim(const SceneView& sc, uint32_t prim, bool bvh) {
 // Traversal order differs from list order, so ties are resolved explicitly by
 // that rule; everything else (each primitive's own candidate t) does not depend
 // on the order of the scan.
-constexpr int kBvhStack = 32;
+constexpr int kBvhStack = 32;  // >= rtxbvh::kMaxDepth + 1: one deferred child per level
 
 RTX_DEV bool tie_wins(uint32_t cand, bool cand_is_rect, uint32_t cur, bool cur_is_rect) {
     if (cand_is_rect && cur_is_rect) return cand > cur;
@@ -466,55 +466,82 @@ RTX_DEV bool tie_wins(uint32_t cand, bool cand_is_rect, uint32_t cur, bool cur_i
     return cand < cur;
 }
 
+// Conservative ray / box test (the builder pads the boxes); returns the entry distance.
+RTX_DEV bool slab(const float lo[3], const float hi[3], V3 o, V3 inv, float t0, float t1, float& t_near) {
+    float tx0 = (lo[0] - o.x) * inv.x, tx1 = (hi[0] - o.x) * inv.x;
+    float ty0 = (lo[1] - o.y) * inv.y, ty1 = (hi[1] - o.y) * inv.y;
+    float tz0 = (lo[2] - o.z) * inv.z, tz1 = (hi[2] - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t0));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), t1));
+    t_near = tn;
+    return tn <= tf;
+}
+
+// Next deferred subtree of this lane, or 0xffffffff when its stack is empty.  An entry that
+// did not fit (the builder bounds the depth, so this does not happen) reads as an empty leaf.
+RTX_DEV uint32_t pop_ref(uint32_t (*stack)[256], uint32_t& sp, uint32_t tid) {
+    if (sp == 0u) return 0xffffffffu;
+    --sp;
+    return sp < (uint32_t)kBvhStack ? stack[sp][tid] : kBvhLeaf;
+}
+
+// Traversal: each lane descends until it holds a leaf (nearer child first, the other one
+// deferred on its stack), then the lanes of the wave test their leaves together.  The stack
+// lives in LDS, one column per thread (entry e of thread t at [e][t]: conflict-free).
 RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec& rec) {
-    uint32_t stack[kBvhStack];
-    int sp = 0;
+    __shared__ uint32_t s_stack[kBvhStack][256];
+    const uint32_t tid = threadIdx.x;
+    uint32_t sp = 0;
     float closest = t1;
     uint32_t best = kNone;
     bool best_is_rect = false;
-    V3 inv = v3(frcp(d.x), frcp(d.y), frcp(d.z));
-    uint32_t node = 0;
+    const V3 inv = v3(frcp(d.x), frcp(d.y), frcp(d.z));
+    constexpr uint32_t kDone = 0xffffffffu;
+    uint32_t ref = 0;  // root node
     for (;;) {
-        const BvhNode N = sc.bvh[node];
-        // slab test, conservative: boxes are padded by the builder
-        float tx0 = (N.lo[0] - o.x) * inv.x, tx1 = (N.hi[0] - o.x) * inv.x;
-        float ty0 = (N.lo[1] - o.y) * inv.y, ty1 = (N.hi[1] - o.y) * inv.y;
-        float tz0 = (N.lo[2] - o.z) * inv.z, tz1 = (N.hi[2] - o.z) * inv.z;
-        float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t0));
-        float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), closest));
-        bool overlap = tn <= tf;
-        if (overlap) {
-            if (N.count == 0) {
-                stack[sp++] = N.left + 1;
-                node = N.left;
-                continue;
+        // descend to a leaf
+        while (ref != kDone && !(ref & kBvhLeaf)) {
+            const BvhNode N = sc.bvh[ref];
+            float n0, n1;
+            const bool h0 = slab(N.lo0, N.hi0, o, inv, t0, closest, n0);
+            const bool h1 = slab(N.lo1, N.hi1, o, inv, t0, closest, n1);
+            if (h0 & h1) {
+                const bool first0 = n0 <= n1;
+                if (sp < (uint32_t)kBvhStack) s_stack[sp][tid] = first0 ? N.child1 : N.child0;
+                ++sp;
+                ref = first0 ? N.child0 : N.child1;
+            } else if (h0 | h1) {
+                ref = h0 ? N.child0 : N.child1;
+            } else {
+                ref = pop_ref(s_stack, sp, tid);
             }
-            for (uint32_t k = 0; k < N.count; ++k) {
-                uint32_t g = sc.bvh_items[N.left + k];
-                const Group G = sc.groups[g];
-                V3 ro = o, rd = d;
-                enter_group<false>(sc, G.step_begin, G.step_end, ro, rd);
-                const RayAux aux = make_aux(ro, rd);
-                for (uint32_t p = G.prim_begin; p < G.prim_end; ++p) {
-                    const Prim P = sc.prims[p];
-                    float t;
-                    bool is_rect = prim_kind(P) != RTX_PRIM_SPHERE;
-                    // candidate t of this primitive alone; the window is inclusive at
-                    // `closest` so that ties reach the explicit rule below
-                    bool ok = prim_test(P, ro, rd, aux, t0, is_rect ? closest : t1, t) && t <= closest;
-                    if (ok) {
-                        bool take = t < closest || best == kNone || tie_wins(p, is_rect, best, best_is_rect);
-                        if (take) {
-                            closest = t;
-                            best = p;
-                            best_is_rect = is_rect;
-                        }
+        }
+        if (ref == kDone) break;
+        // leaf: items [first, first+count)
+        const uint32_t first = ref & kBvhLeafFirst, count = (ref >> kBvhLeafCountShift) & 15u;
+        for (uint32_t k = 0; k < count; ++k) {
+            const Group G = sc.bvh_items[first + k];
+            V3 ro = o, rd = d;
+            enter_group<false>(sc, G.step_begin, G.step_end, ro, rd);
+            const RayAux aux = make_aux(ro, rd);
+            for (uint32_t p = G.prim_begin; p < G.prim_end; ++p) {
+                const Prim P = sc.prims[p];
+                float t;
+                const bool is_rect = prim_kind(P) != RTX_PRIM_SPHERE;
+                // candidate t of this primitive alone; the window is inclusive at
+                // `closest` so that ties reach the explicit rule below
+                const bool ok = prim_test(P, ro, rd, aux, t0, is_rect ? closest : t1, t) && t <= closest;
+                if (ok) {
+                    const bool take = t < closest || best == kNone || tie_wins(p, is_rect, best, best_is_rect);
+                    if (take) {
+                        closest = t;
+                        best = p;
+                        best_is_rect = is_rect;
                     }
                 }
             }
         }
-        if (sp == 0) break;
-        node = stack[--sp];
+        ref = pop_ref(s_stack, sp, tid);
     }
     if (best == kNone) return false;
     finish_hit(sc, best, closest, o, d, rec);

@@ -85,14 +85,19 @@ struct alignas(32) Light {
     uint32_t pad[2];
 };
 
-// BVH over top-level items.  Inner node: count == 0, children at `left`, `left+1`.
-// Leaf: items [left, left+count).
-struct alignas(32) BvhNode {
-    float lo[3];
-    uint32_t left;
-    float hi[3];
-    uint32_t count;
+// BVH over top-level items (a bare primitive, or one transformed instance such as a Box under
+// Rotate / Translate).  A node holds the boxes of BOTH its children, so one 64-byte fetch
+// decides two subtrees.  A child reference is either the index of another node or, with
+// kBvhLeaf set, a leaf: items [ref & kBvhLeafFirst, + ((ref >> 27) & 15)] of `bvh_items`.
+struct alignas(64) BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    uint32_t child0, child1;
+    uint32_t pad[2];
 };
+constexpr uint32_t kBvhLeaf = 0x80000000u;
+constexpr uint32_t kBvhLeafFirst = 0x07ffffffu;
+constexpr uint32_t kBvhLeafCountShift = 27u;
 
 // A BVH item: one group (a bare primitive is a group of one with an empty chain).
 struct SceneView {
@@ -111,7 +116,7 @@ struct SceneView {
     uint32_t n_scan_groups;
     uint32_t scan_pad_;
     const BvhNode* bvh;        // null: linear scan over groups
-    const uint32_t* bvh_items; // group index per BVH leaf slot
+    const Group* bvh_items;    // the groups in leaf order (one load from leaf to primitive range)
     uint32_t n_prims, n_groups, n_steps, n_materials, n_textures, n_lights, n_bvh_nodes;
     uint32_t light_is_list;
     float cam_origin[3], cam_ll[3], cam_u[3], cam_v[3];
