@@ -57,6 +57,17 @@ def load_flops_per_ray(scene: str) -> tuple[float, str]:
         return 375.0, "hand estimate"
 
 
+def load_hbm_traffic(workload: str, spp: int):
+    """HBM bytes per launch of the trace kernel from the PMC passes recorded under profiles/
+    (tools/profile_bench.sh); None when no measurement exists for this exact workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            rec = json.load(f)[workload]
+        return int(rec["bytes_per_launch"]) if rec.get("spp_per_launch") == spp else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(scene: str, w: int, h: int, threads: int, seconds_budget: float = 20.0) -> dict:
     """The reference tracer itself (oracle/_ref), or failing that the CPU restatement, timed on
     this host's cores on a bounded sample of the same workload."""
@@ -230,7 +241,8 @@ def main() -> int:
                 "unit": "TFLOP/s",
                 "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS,
                 "frac_of_nonpacked_peak": achieved_tflops / PEAK_FP32_VALU_NONPACKED_TFLOPS,
-                "traffic": None,
+                "traffic": load_hbm_traffic(args.workload, spp),
+                "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/hbm_traffic.json)",
                 "kernel": "trace_kernel",
                 "kernel_ms_avg": float(np.mean(kernel_ms)),
                 "kernel_ms_min": float(np.min(kernel_ms)),

@@ -32,6 +32,10 @@
 
 #define RTX_DEV __device__ __forceinline__
 
+// threads per block of the trace kernel: 64 (one wave, one 8x8 tile) or 256 (2x2 waves)
+#ifndef RTX_BLOCK
+#define RTX_BLOCK 256
+#endif
 // minimum resident waves per SIMD the trace kernel is compiled for (bounds its VGPR budget)
 #ifndef RTX_TRACE_WAVES
 #define RTX_TRACE_WAVES 4
@@ -489,7 +493,7 @@ RTX_DEV uint32_t pop_ref(uint32_t (*stack)[256], uint32_t& sp, uint32_t tid) {
 // deferred on its stack), then the lanes of the wave test their leaves together.  The stack
 // lives in LDS, one column per thread (entry e of thread t at [e][t]: conflict-free).
 RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec& rec) {
-    __shared__ uint32_t s_stack[kBvhStack][256];
+    __shared__ uint32_t s_stack[kBvhStack][256];  // hit_kernel runs 256 threads; trace blocks use a prefix
     const uint32_t tid = threadIdx.x;
     uint32_t sp = 0;
     float closest = t1;
@@ -824,15 +828,16 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
 // executes in lockstep, so the order of the adds - and with it every bit of the result -
 // is reproducible from run to run.
 template <bool kBvh, bool kSamples>
-__global__ void __launch_bounds__(256, RTX_TRACE_WAVES) trace_kernel(const TraceArgs a) {
-    __shared__ float s_acc[4][3][64];
+__global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES) trace_kernel(const TraceArgs a) {
+    __shared__ float s_acc[RTX_BLOCK / 64][3][64];
     const SceneView& sc = a.scene;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tiles_x = (a.width + 15u) / 16u;
+    constexpr uint32_t kTile = RTX_BLOCK == 256 ? 16u : 8u;  // pixels per block edge
+    const uint32_t tiles_x = (a.width + kTile - 1u) / kTile;
     const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
-    const uint32_t x0 = bx * 16u + (wave & 1u) * 8u;  // tile origin; rows counted from the bottom
-    const uint32_t y0 = by * 16u + (wave >> 1) * 8u;
+    const uint32_t x0 = bx * kTile + (wave & 1u) * 8u;  // tile origin; rows counted from the bottom
+    const uint32_t y0 = by * kTile + (wave >> 1) * 8u;
     if (x0 >= a.width || y0 >= a.height) return;  // wave-uniform
     const uint32_t tw = min(8u, a.width - x0), th = min(8u, a.height - y0);
 
