@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 1u
+#define RTX_ABI_VERSION 2u
 
 typedef enum RtxStatus {
     RTX_OK = 0,
@@ -45,8 +45,8 @@ enum { RTX_LIGHT_RECT_XY = 0, RTX_LIGHT_RECT_XZ = 1, RTX_LIGHT_RECT_YZ = 2, RTX_
 enum { RTX_STEP_TRANSLATE = 0, RTX_STEP_ROTATE = 1 };
 /* Material kinds (Lambertian.h, Metal.h, Dielectric.h, DiffuseLight.h). */
 enum { RTX_MAT_LAMBERTIAN = 0, RTX_MAT_METAL = 1, RTX_MAT_DIELECTRIC = 2, RTX_MAT_DIFFUSE_LIGHT = 3 };
-/* Texture kinds (ColorTexture.h, CheckerTexture.h). */
-enum { RTX_TEX_COLOR = 0, RTX_TEX_CHECKER = 1 };
+/* Texture kinds (ColorTexture.h, CheckerTexture.h, ImageTexture.h). */
+enum { RTX_TEX_COLOR = 0, RTX_TEX_CHECKER = 1, RTX_TEX_IMAGE = 2 };
 /* Acceleration structure choice for rtx_upload_scene(). */
 enum { RTX_ACCEL_AUTO = 0, RTX_ACCEL_LINEAR = 1, RTX_ACCEL_BVH = 2 };
 /* Arithmetic modes of a render. */
@@ -102,8 +102,11 @@ typedef struct RtxScene {
     const float* tex_r;            /* colour: rgb (ColorTexture.h:15)                     */
     const float* tex_g;            /* checker: tex_r = frequency (CheckerTexture.h:18)    */
     const float* tex_b;
-    const uint32_t* tex_odd;       /* checker: sub-texture when the sine product is < 0  */
-    const uint32_t* tex_even;      /* checker: sub-texture otherwise (CheckerTexture.cpp:5-10) */
+    const uint32_t* tex_odd;       /* checker: sub-texture when the sine product is < 0; image: width  */
+    const uint32_t* tex_even;      /* checker: sub-texture otherwise (CheckerTexture.cpp:5-10); image: height */
+    const uint32_t* tex_offset;    /* image: byte offset of its first texel in `texels` (ImageTexture.h:26) */
+    uint64_t n_texel_bytes;        /* may be 0 */
+    const uint8_t* texels;         /* 8-bit RGB, rows top-down, 3 bytes per texel, no padding */
 
     /* light shape handed to Scene::color (Scene.cpp:113) */
     uint32_t n_lights;             /* >= 1 */
@@ -145,6 +148,7 @@ typedef struct RtxHit {
     float p[3];
     float n[3];
     int32_t material;     /* material index, -1 on a miss */
+    float uv[2];          /* texture coordinates (Rect.cpp:27-28, Util.h:78-83) */
 } RtxHit;
 
 typedef struct RtxContext RtxContext;

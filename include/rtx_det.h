@@ -134,4 +134,40 @@ RTX_HD float rtx_tanf(float x)
     return s / c;
 }
 
+/*
+ * fp32 atan2 / asin for the sphere texture coordinates (get_sphere_uv, Util.h:78-83), again
+ * add / sub / mul / div only.  atan on [0,1] is an odd minimax polynomial (error < 2e-7 rad
+ * before rounding), extended by atan(x) = pi/2 - atan(1/x) and the usual quadrant rules; the
+ * square root in rtx_asinf must be IEEE-correct on both sides (it is: sqrtf / v_sqrt with
+ * correct rounding requested).
+ */
+RTX_HD float rtx_atan_unit(float x) /* 0 <= x <= 1 */
+{
+    float z = x * x;
+    float p = 2.78569828e-3f;
+    p = p * z - 1.58660226e-2f;
+    p = p * z + 4.24722321e-2f;
+    p = p * z - 7.49753043e-2f;
+    p = p * z + 1.06448799e-1f;
+    p = p * z - 1.42070308e-1f;
+    p = p * z + 1.99934542e-1f;
+    p = p * z - 3.33331466e-1f;
+    return x + x * z * p;
+}
+
+RTX_HD float rtx_atan2f(float y, float x)
+{
+    float ax = x < 0.0f ? -x : x;
+    float ay = y < 0.0f ? -y : y;
+    float hi = ax > ay ? ax : ay;
+    float lo = ax > ay ? ay : ax;
+    float r = hi == 0.0f ? 0.0f : rtx_atan_unit(lo / hi);
+    if (ay > ax) r = 1.57079632679f - r;
+    if (x < 0.0f) r = 3.14159265359f - r;
+    return y < 0.0f ? -r : r;
+}
+
+/* `root` = sqrtf((1 - x) * (1 + x)) supplied by the caller (the square root is not in this header). */
+RTX_HD float rtx_asinf_with_root(float x, float root) { return rtx_atan2f(x, root); }
+
 #endif /* RTX_DET_H */

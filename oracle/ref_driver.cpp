@@ -29,6 +29,8 @@
 #include "DiffuseLight.h"
 #include "ColorTexture.h"
 #include "CheckerTexture.h"
+#include <stb_image.h> /* declarations only, for ImageTexture.h:9 */
+#include "ImageTexture.h"
 #include <stb_image_write.h> /* declarations only; the implementation is compiled in Scene.cpp:3-6 */
 
 // internal linkage: the renderer's host library includes the same file against its own classes

@@ -13,8 +13,9 @@
  * (Util.h:10) away from glibc's drand48, (c) substitutes rand()/RAND_MAX
  * (Util.h:11) by the counter-based stream of include/rtx_det.h, (d) routes the
  * sin/cos/tan calls that decide path geometry (Util.h:91-92,104-105,
- * CheckerTexture.cpp:4, Camera.h:13, quat_aos.h:352-353) through the
- * bit-reproducible routines of the same header, then (e) includes Pch.h.
+ * CheckerTexture.cpp:4, Camera.h:13, quat_aos.h:352-353) and the atan2/asin of
+ * the sphere texture coordinates (Util.h:79-80) through the bit-reproducible
+ * routines of the same header, then (e) includes Pch.h.
  * No reference source text is copied; the sources are compiled where they lie.
  */
 #ifndef ORACLE_REF_SHIM_H
@@ -58,6 +59,8 @@ static inline int rt_rand()
 static inline float rt_sin(float x) { return rtx_sinf(x); }
 static inline float rt_cos(float x) { return rtx_cosf(x); }
 static inline float rt_tan(float x) { return rtx_tanf(x); }
+static inline float rt_atan2(float y, float x) { return rtx_atan2f(y, x); }
+static inline float rt_asin(float x) { return rtx_asinf_with_root(x, sqrtf((1.0f - x) * (1.0f + x))); }
 
 #define drand48 rt_reference_drand48
 #define rand rt_rand
@@ -68,6 +71,8 @@ static inline float rt_tan(float x) { return rtx_tanf(x); }
 #define tanf rt_tan
 #define sin rt_sin
 #define cos rt_cos
+#define atan2 rt_atan2
+#define asin rt_asin
 
 #include "Pch.h"
 

@@ -116,6 +116,8 @@ struct Hit {  // HitRec.h:3-10
     Vec<F> p, n;
     int prim = -1;
     uint32_t material = 0;
+    float u = 0.0f, v = 0.0f;  // Rect.cpp:27-28, Sphere.cpp:21; never counted as flops (no
+                               // texture of the counted scenes reads them)
 };
 
 // ---------------------------------------------------------------------------
@@ -207,6 +209,7 @@ public:
                     local.n = Vec<F>(kind == RTX_PRIM_RECT_YZ ? 1.0f : 0.0f, kind == RTX_PRIM_RECT_XZ ? 1.0f : 0.0f,
                                      kind == RTX_PRIM_RECT_XY ? 1.0f : 0.0f);  // Rect.cpp:11-13,32
                 }
+                fill_uv(p, kind, ro, rd, t, local);
                 if (sc.prim_flip[p]) local.n = -local.n;  // FlipNormals.cpp:8
                 local.prim = (int)p;
                 local.material = sc.prim_material[p];
@@ -229,12 +232,39 @@ public:
         return any;
     }
 
-    // Texture::value: ColorTexture.h:11-13, CheckerTexture.cpp:3-11
-    Vec<F> texture_value(uint32_t tex, const Vec<F>& p) const {
+    // hrec.u / hrec.v in the primitive's frame: Rect.cpp:21-28, Sphere.cpp:21 + Util.h:78-83
+    void fill_uv(uint32_t p, uint32_t kind, const Vec<F>& ro, const Vec<F>& rd, F t, Hit<F>& h) const {
+        if (kind == RTX_PRIM_SPHERE) {
+            const float nx = raw(h.n.x), ny = raw(h.n.y), nz = raw(h.n.z);
+            float phi = rtx_atan2f(nz, nx);
+            float theta = rtx_asinf_with_root(ny, ::sqrtf((1.0f - ny) * (1.0f + ny)));
+            h.u = 1.f - (phi + kPI) / (2.f * kPI);
+            h.v = (theta + kPI / 2.f) / kPI;
+        } else {
+            const int xi = kind == RTX_PRIM_RECT_YZ ? 1 : 0, yi = kind == RTX_PRIM_RECT_XY ? 1 : 2;
+            float x = raw(ro.at(xi)) + raw(t) * raw(rd.at(xi));
+            float y = raw(ro.at(yi)) + raw(t) * raw(rd.at(yi));
+            h.u = (x - sc.prim_a[p]) / (sc.prim_b[p] - sc.prim_a[p]);
+            h.v = (y - sc.prim_c[p]) / (sc.prim_d[p] - sc.prim_c[p]);
+        }
+    }
+
+    // Texture::value: ColorTexture.h:11-13, CheckerTexture.cpp:3-11, ImageTexture.h:16-29
+    Vec<F> texture_value(uint32_t tex, const Hit<F>& h) const {
         if (sc.tex_kind[tex] == RTX_TEX_COLOR) return Vec<F>(sc.tex_r[tex], sc.tex_g[tex], sc.tex_b[tex]);
+        if (sc.tex_kind[tex] == RTX_TEX_IMAGE) {
+            const int w = (int)sc.tex_odd[tex], hgt = (int)sc.tex_even[tex];
+            int i = (h.u) * w;
+            int j = (1 - h.v) * hgt - 0.001;
+            i = i < 0 ? 0 : i >= w ? w - 1 : i;
+            j = j < 0 ? 0 : j >= hgt ? hgt - 1 : j;
+            const uint8_t* t = sc.texels + sc.tex_offset[tex] + 3 * i + 3 * w * j;
+            return Vec<F>(F((float)(int(t[0]) / 255.0)), F((float)(int(t[1]) / 255.0)), F((float)(int(t[2]) / 255.0)));
+        }
+        const Vec<F>& p = h.p;
         F freq = sc.tex_r[tex];
         F sines = f_sin(freq * p.x) * f_sin(freq * p.y) * f_sin(freq * p.z);
-        return texture_value(sines < F(0.0f) ? sc.tex_odd[tex] : sc.tex_even[tex], p);
+        return texture_value(sines < F(0.0f) ? sc.tex_odd[tex] : sc.tex_even[tex], h);
     }
 
     struct Basis { Vec<F> u, v, w; };
@@ -333,7 +363,7 @@ public:
         const uint32_t kind = sc.mat_kind[m];
         // Material::emitted: Material.h:10, DiffuseLight.h:21-28
         Vec<F> emitted(0.0f, 0.0f, 0.0f);
-        if (kind == RTX_MAT_DIFFUSE_LIGHT && dot(rec.n, d) < F(0.0f)) emitted = texture_value(sc.mat_texture[m], rec.p);
+        if (kind == RTX_MAT_DIFFUSE_LIGHT && dot(rec.n, d) < F(0.0f)) emitted = texture_value(sc.mat_texture[m], rec);
         if (!(depth < m_max_depth)) return emitted;
         switch (kind) {
             case RTX_MAT_DIFFUSE_LIGHT:  // DiffuseLight.h:17-19: scatter() is false
@@ -350,7 +380,7 @@ public:
                     q = Vec<F>(rx, ry, rz) * F(2.0f) - Vec<F>(1.0f, 1.0f, 1.0f);
                 } while (length_sqr(q) >= F(1.0f));
                 reflected = reflected + q * F(sc.mat_param[m]);
-                Vec<F> albedo = texture_value(sc.mat_texture[m], rec.p);
+                Vec<F> albedo = texture_value(sc.mat_texture[m], rec);
                 if (!(dot(reflected, rec.n) > F(0.0f))) return emitted;
                 return emitted + mul_per_elem(albedo, color(rec.p, reflected, depth + 1));  // Scene.cpp:110
             }
@@ -389,7 +419,7 @@ public:
                 return emitted + mul_per_elem(Vec<F>(1.0f, 1.0f, 1.0f), color(rec.p, dir, depth + 1));
             }
             default: {  // Lambertian.cpp:16-25 + Scene.cpp:112-125
-                Vec<F> albedo = texture_value(sc.mat_texture[m], rec.p);
+                Vec<F> albedo = texture_value(sc.mat_texture[m], rec);
                 Vec<F> dir;
                 if (draw() < F(0.5f)) {  // MixturePdf::generate, MixturePdf.h:15-22
                     dir = light_random(rec.p);
@@ -524,6 +554,7 @@ int restate_hit(const RtxScene* scene, uint32_t n, const float* org, const float
             out.t = rec.t;
             out.p[0] = rec.p.x; out.p[1] = rec.p.y; out.p[2] = rec.p.z;
             out.n[0] = rec.n.x; out.n[1] = rec.n.y; out.n[2] = rec.n.z;
+            out.uv[0] = rec.u; out.uv[1] = rec.v;
         }
     }
     return 0;

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "librestate.so")
 _lib = None
 
 HIT_DTYPE = np.dtype([("hit", "<i4"), ("prim", "<i4"), ("t", "<f4"),
-                      ("p", "<f4", (3,)), ("n", "<f4", (3,)), ("material", "<i4")])
+                      ("p", "<f4", (3,)), ("n", "<f4", (3,)), ("material", "<i4"), ("uv", "<f4", (2,))])
 
 
 def available() -> bool:

@@ -15,7 +15,7 @@ import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
-RTX_ABI_VERSION = 1
+RTX_ABI_VERSION = 2
 RTX_ACCEL_AUTO, RTX_ACCEL_LINEAR, RTX_ACCEL_BVH = 0, 1, 2
 RTX_MODE_FAST, RTX_MODE_DETERMINISTIC = 0, 1
 RTX_OK = 0
@@ -44,7 +44,9 @@ class RtxScene(C.Structure):
         ("n_textures", C.c_uint32),
         ("tex_kind", _u32p),
         ("tex_r", _f32p), ("tex_g", _f32p), ("tex_b", _f32p),
-        ("tex_odd", _u32p), ("tex_even", _u32p),
+        ("tex_odd", _u32p), ("tex_even", _u32p), ("tex_offset", _u32p),
+        ("n_texel_bytes", C.c_uint64),
+        ("texels", C.POINTER(C.c_uint8)),
         ("n_lights", C.c_uint32),
         ("light_is_list", C.c_uint32),
         ("light_kind", _u32p),
@@ -69,6 +71,7 @@ class RtxHit(C.Structure):
     _fields_ = [
         ("hit", C.c_int32), ("prim", C.c_int32), ("t", C.c_float),
         ("p", C.c_float * 3), ("n", C.c_float * 3), ("material", C.c_int32),
+        ("uv", C.c_float * 2),
     ]
 
 
@@ -78,7 +81,7 @@ class RtxSceneInfo(C.Structure):
 
 
 HIT_DTYPE = np.dtype([("hit", "<i4"), ("prim", "<i4"), ("t", "<f4"),
-                      ("p", "<f4", (3,)), ("n", "<f4", (3,)), ("material", "<i4")])
+                      ("p", "<f4", (3,)), ("n", "<f4", (3,)), ("material", "<i4"), ("uv", "<f4", (2,))])
 
 #: every symbol include/rtx.h declares
 RTX_SYMBOLS = (
@@ -227,6 +230,7 @@ class HostScene:
                         ("prim_chain", s.n_prims), ("chain_begin", s.n_chains + 1), ("step_kind", s.n_steps),
                         ("mat_kind", s.n_materials), ("mat_texture", s.n_materials),
                         ("tex_kind", s.n_textures), ("tex_odd", s.n_textures), ("tex_even", s.n_textures),
+                        ("tex_offset", s.n_textures),
                         ("light_kind", s.n_lights)):
             out[name] = _as_np(getattr(s, name), n, np.uint32)
         for name, n in (("prim_a", s.n_prims), ("prim_b", s.n_prims), ("prim_c", s.n_prims),
@@ -239,6 +243,7 @@ class HostScene:
         for name in ("cam_origin", "cam_ll", "cam_u", "cam_v", "background"):
             out[name] = np.array(list(getattr(s, name)), np.float32)
         out["light_is_list"] = np.array([s.light_is_list], np.uint32)
+        out["texels"] = _as_np(s.texels, int(s.n_texel_bytes), np.uint8)
         return out
 
 

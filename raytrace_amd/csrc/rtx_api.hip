@@ -68,6 +68,7 @@ struct RtxContext {
     DeviceArray<rtxd::Step> steps;
     DeviceArray<rtxd::Material> materials;
     DeviceArray<rtxd::Texture> textures;
+    DeviceArray<uint8_t> texels;
     DeviceArray<rtxd::Light> lights;
     DeviceArray<rtxd::ScanGroup> scan_groups;
     DeviceArray<rtxd::ScanRec> scan_recs;
@@ -112,8 +113,10 @@ int check_scene(const RtxScene* s) {
         return fail(RTX_ERR_INVALID_ARGUMENT, "a step array is null");
     if (s->n_materials == 0 || !s->mat_kind || !s->mat_texture || !s->mat_param)
         return fail(RTX_ERR_INVALID_ARGUMENT, "material table missing");
-    if (s->n_textures && (!s->tex_kind || !s->tex_r || !s->tex_g || !s->tex_b || !s->tex_odd || !s->tex_even))
+    if (s->n_textures && (!s->tex_kind || !s->tex_r || !s->tex_g || !s->tex_b || !s->tex_odd || !s->tex_even ||
+                          !s->tex_offset))
         return fail(RTX_ERR_INVALID_ARGUMENT, "a texture array is null");
+    if (s->n_texel_bytes && !s->texels) return fail(RTX_ERR_INVALID_ARGUMENT, "texels is null");
     if (!s->light_kind || !s->light_a || !s->light_b || !s->light_c || !s->light_d || !s->light_e)
         return fail(RTX_ERR_INVALID_ARGUMENT, "a light array is null");
     for (uint32_t p = 0; p < s->n_prims; ++p) {
@@ -130,7 +133,12 @@ int check_scene(const RtxScene* s) {
             return fail(RTX_ERR_INVALID_ARGUMENT, "mat_texture out of range");
     }
     for (uint32_t t = 0; t < s->n_textures; ++t) {
-        if (s->tex_kind[t] > RTX_TEX_CHECKER) return fail(RTX_ERR_INVALID_ARGUMENT, "bad tex_kind");
+        if (s->tex_kind[t] > RTX_TEX_IMAGE) return fail(RTX_ERR_INVALID_ARGUMENT, "bad tex_kind");
+        if (s->tex_kind[t] == RTX_TEX_IMAGE) {
+            const uint64_t need = (uint64_t)s->tex_odd[t] * s->tex_even[t] * 3u;
+            if (need == 0 || (uint64_t)s->tex_offset[t] + need > s->n_texel_bytes)
+                return fail(RTX_ERR_INVALID_ARGUMENT, "image texture outside the texel buffer");
+        }
         if (s->tex_kind[t] == RTX_TEX_CHECKER &&
             (s->tex_odd[t] >= s->n_textures || s->tex_even[t] >= s->n_textures))
             return fail(RTX_ERR_INVALID_ARGUMENT, "checker sub-texture out of range");
@@ -140,6 +148,15 @@ int check_scene(const RtxScene* s) {
     if (!s->light_is_list && s->n_lights != 1)
         return fail(RTX_ERR_INVALID_ARGUMENT, "a bare (non-list) light shape must have exactly one entry");
     return RTX_OK;
+}
+
+// True if texture t or any checker sub-texture of it is an image (which reads (u, v)).
+bool texture_needs_uv(const RtxScene* s, uint32_t t, int depth) {
+    if (depth > 16) return false;
+    if (s->tex_kind[t] == RTX_TEX_IMAGE) return true;
+    if (s->tex_kind[t] == RTX_TEX_CHECKER)
+        return texture_needs_uv(s, s->tex_odd[t], depth + 1) || texture_needs_uv(s, s->tex_even[t], depth + 1);
+    return false;
 }
 
 // Compose a group's step chain (outermost wrapper first) into one world->group affine map.
@@ -319,7 +336,8 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
         T.kind = s->tex_kind[t];
         T.r = s->tex_r[t]; T.g = s->tex_g[t]; T.b = s->tex_b[t];
         T.odd = s->tex_odd[t]; T.even = s->tex_even[t];
-        T.pad[0] = T.pad[1] = 0;
+        T.offset = s->tex_offset[t];
+        T.pad = 0;
     }
     std::vector<rtxd::Light> lights(s->n_lights);
     for (uint32_t l = 0; l < s->n_lights; ++l) {
@@ -345,6 +363,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
                 I.r = s->tex_r[t]; I.g = s->tex_g[t]; I.b = s->tex_b[t];
             } else {
                 I.bits |= rtxd::kInfoTextured;
+                if (texture_needs_uv(s, t, 0)) I.bits |= rtxd::kInfoNeedsUV;
             }
         }
         const uint32_t c = s->prim_chain[p];
@@ -373,6 +392,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     RTX_HIP(ctx->steps.upload(steps));
     RTX_HIP(ctx->materials.upload(mats));
     RTX_HIP(ctx->textures.upload(texs));
+    RTX_HIP(ctx->texels.upload(std::vector<uint8_t>(s->texels, s->texels + s->n_texel_bytes)));
     RTX_HIP(ctx->lights.upload(lights));
     RTX_HIP(ctx->scan_groups.upload(scan_groups));
     RTX_HIP(ctx->scan_recs.upload(scan_recs));
@@ -388,6 +408,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     v.steps = ctx->steps.ptr;
     v.materials = ctx->materials.ptr;
     v.textures = ctx->textures.ptr;
+    v.texels = ctx->texels.ptr;
     v.lights = ctx->lights.ptr;
     v.scan_groups = use_bvh ? nullptr : ctx->scan_groups.ptr;
     v.scan_recs = use_bvh ? nullptr : ctx->scan_recs.ptr;

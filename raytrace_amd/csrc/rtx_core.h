@@ -135,6 +135,7 @@ struct HitRec {
     uint32_t texture;
     float param;
     V3 color;
+    float u, v;  // texture coordinates; only valid when asked for or when the texture needs them
 };
 RTX_DEV uint32_t rec_mat_kind(const HitRec& r) { return (r.bits >> kInfoMatShift) & 3u; }
 
@@ -254,15 +255,37 @@ RTX_DEV void enter_group(const SceneView& sc, uint32_t step_begin, uint32_t step
     }
 }
 
+// Texture coordinates of a rect hit (Rect.cpp:27-28) from the in-plane coordinates of the
+// hit point in the rect's frame, and of a sphere hit (get_sphere_uv, Util.h:78-83) from the
+// unit normal in the sphere's frame, before FlipNormals.
+RTX_DEV void rect_uv(uint32_t kind, float x0, float x1, float y0, float y1, V3 ro, V3 rd, float t, float& u,
+                     float& v) {
+    const int xi = kind == RTX_PRIM_RECT_YZ ? 1 : 0, yi = kind == RTX_PRIM_RECT_XY ? 1 : 2;
+    const float ox = xi == 0 ? ro.x : ro.y, dx = xi == 0 ? rd.x : rd.y;
+    const float oy = yi == 1 ? ro.y : ro.z, dy = yi == 1 ? rd.y : rd.z;
+    float x = ox + t * dx;
+    float y = oy + t * dy;
+    u = fdiv(x - x0, x1 - x0);
+    v = fdiv(y - y0, y1 - y0);
+}
+RTX_DEV void sphere_uv(V3 n, float& u, float& v) {
+    constexpr float kPi = 3.14159265359f;  // PI, Util.h:2
+    float phi = rtx_atan2f(n.z, n.x);
+    float theta = rtx_asinf_with_root(n.y, __builtin_sqrtf((1.0f - n.y) * (1.0f + n.y)));
+    u = 1.0f - fdiv(phi + kPi, 2.0f * kPi);
+    v = fdiv(theta + fdiv(kPi, 2.0f), kPi);
+}
+
 // Complete the record of the winning primitive (per lane).  In the reference the record is
 // filled in the primitive's frame (Rect.cpp:27-32, Sphere.cpp:17-20) and carried out through
 // the wrappers innermost first: Rotate::hit (Rotate.cpp:12-13) rotates p and n,
 // Translate::hit (Translate.cpp:9) offsets p, FlipNormals::hit (FlipNormals.cpp:8) negates n.
-RTX_DEV void finish_hit(const SceneView& sc, uint32_t prim, float t, V3 o, V3 d, HitRec& rec) {
+RTX_DEV void finish_hit(const SceneView& sc, uint32_t prim, float t, V3 o, V3 d, bool want_uv, HitRec& rec) {
     const PrimInfo I = sc.info[prim];  // two independent loads, one wait
     const Prim W = sc.prims[prim];
     const uint32_t kind = I.bits & kInfoKindMask;
     const bool chained = I.step_end > I.step_begin;
+    const bool uv = want_uv || (I.bits & kInfoNeedsUV);
     V3 ro = o, rd = d;
 #if RTX_DET
     if (chained) enter_group<false>(sc, I.step_begin, I.step_end, ro, rd);
@@ -273,21 +296,24 @@ RTX_DEV void finish_hit(const SceneView& sc, uint32_t prim, float t, V3 o, V3 d,
     // local point is only needed for a sphere's normal
     V3 p = o + d * t;
     V3 pl = p;
-    if (chained && kind == RTX_PRIM_SPHERE) {
+    if (chained && (kind == RTX_PRIM_SPHERE || uv)) {
         enter_group<false>(sc, I.step_begin, I.step_end, ro, rd);
         pl = ro + rd * t;
     }
 #endif
     V3 n;
+    rec.u = rec.v = 0.0f;
     if (kind == RTX_PRIM_SPHERE) {
 #if RTX_DET
         n = vdivs(pl - v3(W.a, W.b, W.c), W.d);  // Sphere.cpp:19
 #else
         n = (pl - v3(W.a, W.b, W.c)) * frcp(W.d);
 #endif
+        if (uv) sphere_uv(n, rec.u, rec.v);  // Sphere.cpp:21
     } else {
         n = v3(kind == RTX_PRIM_RECT_YZ ? 1.0f : 0.0f, kind == RTX_PRIM_RECT_XZ ? 1.0f : 0.0f,
                kind == RTX_PRIM_RECT_XY ? 1.0f : 0.0f);
+        if (uv) rect_uv(kind, W.a, W.b, W.c, W.d, ro, rd, t, rec.u, rec.v);
     }
     if (I.bits & kInfoFlip) n = -n;
     if (chained) {
@@ -325,7 +351,7 @@ RTX_DEV void finish_hit(const SceneView& sc, uint32_t prim, float t, V3 o, V3 d,
 // Deterministic mode: list order, one generic loop (the order decides ties and the fate of
 // NaN candidates, both of which must come out as in the reference).  The next record is
 // requested before the current one is tested.
-RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec& rec) {
+RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool want_uv, HitRec& rec) {
     float closest = t1;
     uint32_t best = kNone;
     for (uint32_t g = 0; g < sc.n_groups; ++g) {
@@ -345,7 +371,7 @@ RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, Hit
         }
     }
     if (best == kNone) return false;
-    finish_hit(sc, best, closest, o, d, rec);
+    finish_hit(sc, best, closest, o, d, want_uv, rec);
     return true;
 }
 RTX_DEV uint32_t original_prim(const SceneView&, uint32_t prim, bool) { return prim; }
@@ -366,7 +392,7 @@ RTX_DEV void scan_rects(const SceneView& sc, uint32_t& pos, uint32_t count, V3 r
     }
 }
 
-RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec& rec) {
+RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool want_uv, HitRec& rec) {
     float closest = t1;
     uint32_t best = kNone;
     for (uint32_t g = 0; g < sc.n_scan_groups; ++g) {
@@ -413,24 +439,28 @@ RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, Hit
     const ScanRec W = sc.scan_recs[best];
     const uint32_t kind = I.bits & kInfoKindMask;
     const bool chained = I.step_end != I.step_begin;
+    const bool uv = want_uv || (I.bits & kInfoNeedsUV);
     const V3 p = o + d * closest;
     float m[9];
     if (chained) {
         const ScanGroup* G = sc.scan_groups + I.step_begin;
         for (int k = 0; k < 9; ++k) m[k] = G->m[k];
     }
+    V3 pl = p;  // the hit point in the primitive's frame
+    if (chained && (kind == RTX_PRIM_SPHERE || uv)) {
+        const ScanGroup* G = sc.scan_groups + I.step_begin;
+        pl = v3(m[0] * p.x + m[1] * p.y + m[2] * p.z + G->m[9], m[3] * p.x + m[4] * p.y + m[5] * p.z + G->m[10],
+                m[6] * p.x + m[7] * p.y + m[8] * p.z + G->m[11]);
+    }
     V3 n;
+    rec.u = rec.v = 0.0f;
     if (kind == RTX_PRIM_SPHERE) {
-        V3 pl = p;
-        if (chained) {
-            const ScanGroup* G = sc.scan_groups + I.step_begin;
-            pl = v3(m[0] * p.x + m[1] * p.y + m[2] * p.z + G->m[9], m[3] * p.x + m[4] * p.y + m[5] * p.z + G->m[10],
-                    m[6] * p.x + m[7] * p.y + m[8] * p.z + G->m[11]);
-        }
         n = (pl - v3(W.a, W.b, W.c)) * frcp(W.d);
+        if (uv) sphere_uv(n, rec.u, rec.v);
     } else {
         n = v3(kind == RTX_PRIM_RECT_YZ ? 1.0f : 0.0f, kind == RTX_PRIM_RECT_XZ ? 1.0f : 0.0f,
                kind == RTX_PRIM_RECT_XY ? 1.0f : 0.0f);
+        if (uv) rect_uv(kind, W.a, W.b, W.c, W.d, pl, v3(0.0f, 0.0f, 0.0f), 0.0f, rec.u, rec.v);
     }
     if (I.bits & kInfoFlip) n = -n;
     if (chained)  // back to world space: the transpose of the world->group rotation
@@ -492,7 +522,7 @@ RTX_DEV uint32_t pop_ref(uint32_t (*stack)[256], uint32_t& sp, uint32_t tid) {
 // Traversal: each lane descends until it holds a leaf (nearer child first, the other one
 // deferred on its stack), then the lanes of the wave test their leaves together.  The stack
 // lives in LDS, one column per thread (entry e of thread t at [e][t]: conflict-free).
-RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec& rec) {
+RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool want_uv, HitRec& rec) {
     __shared__ uint32_t s_stack[kBvhStack][256];  // hit_kernel runs 256 threads; trace blocks use a prefix
     const uint32_t tid = threadIdx.x;
     uint32_t sp = 0;
@@ -548,24 +578,44 @@ RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec
         ref = pop_ref(s_stack, sp, tid);
     }
     if (best == kNone) return false;
-    finish_hit(sc, best, closest, o, d, rec);
+    finish_hit(sc, best, closest, o, d, want_uv, rec);
     return true;
 }
 
+// want_uv: fill the texture coordinates even when the hit's texture does not read them.
 template <bool kBvh>
-RTX_DEV bool scene_hit(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec& rec) {
-    if (kBvh) return hit_bvh(sc, o, d, t0, t1, rec);
-    return hit_linear(sc, o, d, t0, t1, rec);
+RTX_DEV bool scene_hit(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec& rec, bool want_uv = false) {
+    if (kBvh) return hit_bvh(sc, o, d, t0, t1, want_uv, rec);
+    return hit_linear(sc, o, d, t0, t1, want_uv, rec);
 }
 
 // ---------------------------------------------------------------------------
-// textures (Texture.h:5): ColorTexture.h:11-13, CheckerTexture.cpp:3-11
+// textures (Texture.h:5): ColorTexture.h:11-13, CheckerTexture.cpp:3-11, ImageTexture.h:16-29
 // ---------------------------------------------------------------------------
-RTX_DEV V3 texture_value(const SceneView& sc, uint32_t tex, V3 p) {
+RTX_DEV V3 image_value(const SceneView& sc, const Texture& T, float u, float v) {
+    const int w = (int)T.odd, h = (int)T.even;
+    int i = (int)(u * (float)w);  // ImageTexture.h:17
+#if RTX_DET
+    int j = (int)((double)((1.0f - v) * (float)h) - 0.001);  // ImageTexture.h:18 (the literal is a double)
+#else
+    int j = (int)((1.0f - v) * (float)h - 0.001f);
+#endif
+    i = i < 0 ? 0 : (i >= w ? w - 1 : i);  // ImageTexture.h:23-24
+    j = j < 0 ? 0 : (j >= h ? h - 1 : j);
+    const uint8_t* t = sc.texels + T.offset + 3u * (uint32_t)i + 3u * (uint32_t)w * (uint32_t)j;
+#if RTX_DET
+    return v3((float)((double)t[0] / 255.0), (float)((double)t[1] / 255.0), (float)((double)t[2] / 255.0));
+#else
+    return v3((float)t[0], (float)t[1], (float)t[2]) * (1.0f / 255.0f);
+#endif
+}
+
+RTX_DEV V3 texture_value(const SceneView& sc, uint32_t tex, float u, float v, V3 p) {
 #pragma unroll 1
     for (int level = 0; level < 16; ++level) {  // nesting depth of CheckerTexture sub-textures
         const Texture T = sc.textures[tex];
         if (T.kind == RTX_TEX_COLOR) return v3(T.r, T.g, T.b);
+        if (T.kind == RTX_TEX_IMAGE) return image_value(sc, T, u, v);
         float sines = (fsin(T.r * p.x) * fsin(T.r * p.y)) * fsin(T.r * p.z);
         tex = sines < 0.0f ? T.odd : T.even;
     }
@@ -574,7 +624,7 @@ RTX_DEV V3 texture_value(const SceneView& sc, uint32_t tex, V3 p) {
 
 // Texture::value of the hit's material texture: plain colours come with the hit record.
 RTX_DEV V3 surface_color(const SceneView& sc, const HitRec& rec) {
-    if (rec.bits & kInfoTextured) return texture_value(sc, rec.texture, rec.p);
+    if (rec.bits & kInfoTextured) return texture_value(sc, rec.texture, rec.u, rec.v, rec.p);
     return rec.color;
 }
 
@@ -945,7 +995,8 @@ __global__ void __launch_bounds__(256) hit_kernel(const HitArgs a) {
     rec.t = 0.0f;
     rec.p = rec.n = v3(0.0f, 0.0f, 0.0f);
     rec.prim = kNone;
-    bool hit = scene_hit<kBvh>(a.scene, o, d, a.t0, a.t1, rec);
+    rec.u = rec.v = 0.0f;
+    bool hit = scene_hit<kBvh>(a.scene, o, d, a.t0, a.t1, rec, true);
     if (k < a.n) {
         RtxHit* out = reinterpret_cast<RtxHit*>(a.hits) + k;
         out->hit = hit ? 1 : 0;
@@ -959,6 +1010,8 @@ __global__ void __launch_bounds__(256) hit_kernel(const HitArgs a) {
         out->n[1] = hit ? rec.n.y : 0.0f;
         out->n[2] = hit ? rec.n.z : 0.0f;
         out->material = hit ? (int32_t)a.scene.prims[prim].material : -1;
+        out->uv[0] = hit ? rec.u : 0.0f;
+        out->uv[1] = hit ? rec.v : 0.0f;
     }
 }
 

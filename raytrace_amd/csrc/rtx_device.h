@@ -34,6 +34,7 @@ constexpr uint32_t kInfoKindMask = 3u;       // RTX_PRIM_*
 constexpr uint32_t kInfoFlip = 4u;           // FlipNormals parity
 constexpr uint32_t kInfoMatShift = 3u;       // RTX_MAT_* in bits 3-4
 constexpr uint32_t kInfoTextured = 32u;      // texture is not a plain colour: evaluate it
+constexpr uint32_t kInfoNeedsUV = 64u;       // ... and it (or a sub-texture) is an image: needs (u, v)
 
 // Fast-mode linear scan: the primitives of a group re-ordered by kind (XY rects, XZ rects,
 // YZ rects, spheres) so that each kind is scanned by a branch-free loop over homogeneous
@@ -73,10 +74,11 @@ struct alignas(16) Material {
 };
 
 struct alignas(32) Texture {
-    uint32_t kind;  // RTX_TEX_*
-    float r, g, b;  // colour; checker: r = frequency
-    uint32_t odd, even;
-    uint32_t pad[2];
+    uint32_t kind;       // RTX_TEX_*
+    float r, g, b;       // colour; checker: r = frequency
+    uint32_t odd, even;  // checker: sub-textures; image: width, height
+    uint32_t offset;     // image: byte offset of the first texel
+    uint32_t pad;
 };
 
 struct alignas(32) Light {
@@ -107,6 +109,7 @@ struct SceneView {
     const Step* steps;
     const Material* materials;
     const Texture* textures;
+    const uint8_t* texels;  // 8-bit RGB image data of all image textures
     const Light* lights;
     // bucketed copy for the fast-mode linear scan (null when a BVH is used)
     const ScanGroup* scan_groups;

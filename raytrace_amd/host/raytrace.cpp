@@ -130,7 +130,15 @@ uint32_t FlatScene::new_texture(uint32_t kind, float r, float g, float b, uint32
     tex_b.push_back(b);
     tex_odd.push_back(odd);
     tex_even.push_back(even);
+    tex_offset.push_back(0);
     return (uint32_t)tex_kind.size() - 1;
+}
+
+uint32_t FlatScene::new_image_texture(int width, int height, const unsigned char* rgb) {
+    const uint32_t id = new_texture(RTX_TEX_IMAGE, 0.0f, 0.0f, 0.0f, (uint32_t)width, (uint32_t)height);
+    tex_offset[id] = (uint32_t)texels.size();
+    texels.insert(texels.end(), rgb, rgb + (size_t)width * height * 3);
+    return id;
 }
 
 uint32_t FlatScene::new_material(uint32_t kind, uint32_t tex, float param) {
@@ -187,6 +195,9 @@ const RtxScene* FlatScene::view() {
     s.tex_b = tex_b.data();
     s.tex_odd = tex_odd.data();
     s.tex_even = tex_even.data();
+    s.tex_offset = tex_offset.data();
+    s.n_texel_bytes = texels.size();
+    s.texels = texels.data();
     s.n_lights = (uint32_t)light_kind.size();
     s.light_is_list = m_light_is_list ? 1u : 0u;
     s.light_kind = light_kind.data();
@@ -214,6 +225,83 @@ uint32_t CheckerTexture::flatten(FlatScene& f) const {
     uint32_t odd = f.intern_texture(m_odd);
     uint32_t even = f.intern_texture(m_even);
     return f.new_texture(RTX_TEX_CHECKER, m_freq, 0.0f, 0.0f, odd, even);
+}
+
+// ---------------------------------------------------------------------------
+// image textures
+// ---------------------------------------------------------------------------
+namespace {
+uint32_t rd32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+bool load_bmp(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgb) {
+    if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') return false;
+    const uint32_t off = rd32(&d[10]);
+    const int32_t bw = (int32_t)rd32(&d[18]), bh = (int32_t)rd32(&d[22]);
+    const uint32_t bpp = d[28] | (d[29] << 8), compression = rd32(&d[30]);
+    if (bpp != 24 || compression != 0 || bw <= 0 || bh == 0) return false;
+    w = bw;
+    h = bh < 0 ? -bh : bh;
+    const size_t stride = ((size_t)w * 3 + 3) & ~(size_t)3;
+    if (d.size() < off + stride * h) return false;
+    rgb.resize((size_t)w * h * 3);
+    for (int y = 0; y < h; ++y) {
+        const int src_row = bh > 0 ? h - 1 - y : y;  // positive height: bottom-up file
+        const unsigned char* src = &d[off + stride * src_row];
+        for (int x = 0; x < w; ++x) {
+            rgb[((size_t)y * w + x) * 3 + 0] = src[3 * x + 2];
+            rgb[((size_t)y * w + x) * 3 + 1] = src[3 * x + 1];
+            rgb[((size_t)y * w + x) * 3 + 2] = src[3 * x + 0];
+        }
+    }
+    return true;
+}
+
+bool load_ppm(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgb) {
+    if (d.size() < 11 || d[0] != 'P' || d[1] != '6') return false;
+    size_t pos = 2;
+    int vals[3], got = 0;
+    while (got < 3 && pos < d.size()) {
+        while (pos < d.size() && (d[pos] == ' ' || d[pos] == '\n' || d[pos] == '\r' || d[pos] == '\t')) ++pos;
+        if (pos < d.size() && d[pos] == '#') { while (pos < d.size() && d[pos] != '\n') ++pos; continue; }
+        int v = 0;
+        bool any = false;
+        while (pos < d.size() && d[pos] >= '0' && d[pos] <= '9') { v = v * 10 + (d[pos] - '0'); ++pos; any = true; }
+        if (!any) return false;
+        vals[got++] = v;
+    }
+    if (got < 3 || vals[2] != 255 || vals[0] <= 0 || vals[1] <= 0) return false;
+    ++pos;  // the single whitespace after maxval
+    w = vals[0];
+    h = vals[1];
+    if (d.size() < pos + (size_t)w * h * 3) return false;
+    rgb.assign(d.begin() + pos, d.begin() + pos + (size_t)w * h * 3);
+    return true;
+}
+}  // namespace
+
+ImageTexture::ImageTexture(const char* name) : m_name(name ? name : "") {
+    FILE* fp = name ? std::fopen(name, "rb") : nullptr;
+    if (!fp) return;
+    std::vector<unsigned char> data;
+    unsigned char buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, fp)) > 0) data.insert(data.end(), buf, buf + n);
+    std::fclose(fp);
+    if (!load_bmp(data, m_width, m_height, m_texels) && !load_ppm(data, m_width, m_height, m_texels)) {
+        m_width = m_height = 0;
+        m_texels.clear();
+    }
+}
+
+ImageTexture::ImageTexture(int width, int height, const unsigned char* rgb)
+    : m_width(width), m_height(height), m_texels(rgb, rgb + (size_t)width * height * 3), m_name("<memory>") {}
+
+uint32_t ImageTexture::flatten(FlatScene& f) const {
+    if (!loaded()) {
+        f.fail("ImageTexture '" + m_name + "': cannot read (24-bit BMP and binary PPM are supported)");
+        return 0;
+    }
+    return f.new_image_texture(m_width, m_height, m_texels.data());
 }
 
 uint32_t Lambertian::flatten(FlatScene& f) const {

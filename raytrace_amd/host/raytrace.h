@@ -115,6 +115,8 @@ public:
     uint32_t intern_material(const MaterialPtr& m);
     uint32_t intern_texture(const TexturePtr& t);
     uint32_t new_texture(uint32_t kind, float r, float g, float b, uint32_t odd, uint32_t even);
+    // 8-bit RGB image texture; returns the texture index
+    uint32_t new_image_texture(int width, int height, const unsigned char* rgb);
     uint32_t new_material(uint32_t kind, uint32_t tex, float param);
     void set_camera(const Camera& cam);
     void set_background(const Vector3& c);
@@ -128,7 +130,8 @@ public:
     std::vector<float> step_x, step_y, step_z, step_w;
     std::vector<uint32_t> mat_kind, mat_texture;
     std::vector<float> mat_param;
-    std::vector<uint32_t> tex_kind, tex_odd, tex_even;
+    std::vector<uint32_t> tex_kind, tex_odd, tex_even, tex_offset;
+    std::vector<uint8_t> texels;
     std::vector<float> tex_r, tex_g, tex_b;
     std::vector<uint32_t> light_kind;
     std::vector<float> light_a, light_b, light_c, light_d, light_e;
@@ -170,6 +173,24 @@ public:
 private:
     TexturePtr m_odd, m_even;
     float m_freq;
+};
+
+// ImageTexture.h: nearest-texel lookup into an 8-bit RGB image.  The reference decodes the
+// file with stb_image (JPEG, PNG, ...); this class reads 24-bit uncompressed BMP and binary
+// PPM (P6) files, or takes the texels directly.
+class ImageTexture : public Texture {
+public:
+    ImageTexture(const char* name);
+    ImageTexture(int width, int height, const unsigned char* rgb);
+    uint32_t flatten(FlatScene& f) const override;
+    int width() const { return m_width; }
+    int height() const { return m_height; }
+    bool loaded() const { return !m_texels.empty(); }
+
+private:
+    int m_width = 0, m_height = 0;
+    std::vector<unsigned char> m_texels;  // rows top-down, RGB
+    std::string m_name;
 };
 
 // ---------------------------------------------------------------------------

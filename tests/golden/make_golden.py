@@ -4,7 +4,9 @@
 oracle/Makefile, fed the counter-based stream of include/rtx_det.h).
 
 Run from the repository root in a container that holds /root/reference:
-    make -C oracle && python tests/golden/make_golden.py
+    make -C oracle && python tests/golden/make_golden.py [section ...]
+(sections: texture samples hits misc flops gt; default all; "samples:textured" and
+"hits:textured" restrict a section to one scene).
 The reference has no fixtures of its own for this path, so these files are what pins
 the CPU restatement (and through it the GPU path) wherever the reference is absent.
 Only data is stored: inputs (scene names, seeds, rays) and the reference's outputs.
@@ -30,11 +32,31 @@ SAMPLE_CASES = [  # scene, w, h, spp_begin, spp, seed
     ("small", 32, 18, 0, 8, 7),
     ("random_field", 32, 18, 0, 4, 7),
     ("bvh_stress_500", 24, 14, 0, 2, 7),
+    ("textured", 48, 27, 0, 8, 7),
 ]
+HIT_SCENES = ("cornell", "cornell_extra", "random_field", "bvh_stress_500", "textured")
+TEXTURE = os.path.join(HERE, "texture_64x32.bmp")
+
+
+def write_texture_fixture():
+    """A 64x32 24-bit BMP (bottom-up rows, BGR) with no two neighbouring texels alike, so a
+    texel-index error of one shows up."""
+    w, h = 64, 32
+    y, x = np.mgrid[0:h, 0:w]
+    rgb = np.stack([(x * 4 + (y % 2) * 2) % 256, (y * 8 + (x % 3) * 3) % 256, ((x * 7) ^ (y * 13)) % 256], -1).astype(np.uint8)
+    rgb = np.maximum(rgb, 24)  # keep albedos away from 0 so paths survive
+    row = w * 3
+    assert row % 4 == 0
+    import struct
+    header = b"BM" + struct.pack("<IHHI", 54 + row * h, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, row * h, 2835, 2835, 0, 0)
+    body = rgb[::-1, :, ::-1].tobytes()
+    with open(TEXTURE, "wb") as f:
+        f.write(header + body)
+    return rgb
 
 
 def rays_for(name, n, rng):
-    if name.startswith("cornell"):
+    if name.startswith("cornell") or name == "textured":
         o = rng.uniform(1, 554, (n, 3)).astype(np.float32)
     elif name.startswith("bvh_stress"):
         o = rng.uniform(0, 100, (n, 3)).astype(np.float32)
@@ -50,10 +72,21 @@ def rays_for(name, n, rng):
     return o, d
 
 
-def main():
+def main(argv):
     assert ref.available(), "build oracle/_ref first"
-    out = {}
+    sections = argv or ["texture", "samples", "hits", "misc", "flops", "gt"]
+
+    def want(section, scene=None):
+        return section in sections or (scene is not None and f"{section}:{scene}" in sections)
+
+    os.environ["RTX_TEXTURE"] = TEXTURE
+    if want("texture"):
+        write_texture_fixture()
+    index_path = os.path.join(HERE, "index.json")
+    out = json.load(open(index_path)) if os.path.exists(index_path) else {}
     for name, w, h, s0, spp, seed in SAMPLE_CASES:
+        if not want("samples", name):
+            continue
         r = ref.RefScene(name, w, h).render(s0, spp, seed=seed, threads=8, per_sample=True)
         key = f"samples_{name}_{w}x{h}_s{s0}+{spp}_seed{seed}"
         np.savez_compressed(os.path.join(HERE, key + ".npz"), samples=r["samples"], segments=r["segments"].astype(np.uint8)
@@ -62,16 +95,30 @@ def main():
         out[key] = dict(scene=name, w=w, h=h, spp_begin=s0, spp=spp, seed=seed, rays=int(r["rays"]))
         print(key, r["rays"])
 
+    with open(index_path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
     rng = np.random.default_rng(2024)
-    for name in ("cornell", "cornell_extra", "random_field", "bvh_stress_500"):
-        o, d = rays_for(name, 4096, rng)
+    for name in HIT_SCENES:
+        o, d = rays_for(name, 4096, rng)  # always drawn, so every scene keeps its rays
+        if not want("hits", name):
+            continue
         hrec = ref.RefScene(name, 32, 32).hit(o, d)
         # tie cases: rays from the box corner along wall intersections etc. are covered by the
         # axis-aligned directions above; add rays that start exactly on a wall plane
         np.savez_compressed(os.path.join(HERE, f"hits_{name}.npz"), origins=o, directions=d, hit=hrec["hit"].astype(np.uint8),
-                            t=hrec["t"], p=hrec["p"], n=hrec["n"], mat_kind=hrec["mat_kind"].astype(np.int8))
+                            t=hrec["t"], p=hrec["p"], n=hrec["n"], uv=hrec["uv"], mat_kind=hrec["mat_kind"].astype(np.int8))
         print("hits", name, int(hrec["hit"].sum()))
 
+    if want("misc"):
+        misc(np.random.default_rng(2026))
+    if want("flops"):
+        flops_per_ray()
+    if want("gt"):
+        ground_truth()
+
+
+def misc(rng):
     # Image::write table incl. NaN / negative / > 1 / inf
     x = rng.normal(0.3, 0.6, (4096, 3)).astype(np.float32)
     x[5, 1] = np.nan
@@ -96,12 +143,8 @@ def main():
     ref.write_bmp("/tmp/_golden.bmp", img)
     np.savez_compressed(os.path.join(HERE, "bmp_7x5.npz"), rgb8=img, bmp_bytes=np.frombuffer(open("/tmp/_golden.bmp", "rb").read(), np.uint8))
 
-    # known answers of the random stream / sincos contract (include/rtx_det.h), from the
-    # reference build's own draws: first 8 draws of a few (pixel, sample, seed) keys are implied
-    # by the per-sample fixtures above; keep the file list
-    with open(os.path.join(HERE, "index.json"), "w") as f:
-        json.dump(out, f, indent=1, sort_keys=True)
 
+def flops_per_ray():
     # algorithmic flops per ray (op-counting build of the CPU restatement) per scene
     flops = {}
     for name, w, h, spp in (("cornell", 480, 270, 8), ("cornell_classic", 480, 270, 8), ("cornell_extra", 480, 270, 8),
@@ -114,6 +157,8 @@ def main():
     with open(os.path.join(HERE, "flops_per_ray.json"), "w") as f:
         json.dump(flops, f, indent=1, sort_keys=True)
 
+
+def ground_truth():
     # high-spp ground truth for the fast-mode statistical test
     w, h, spp = 160, 90, 4096
     hs = api.HostScene("cornell", w, h)
@@ -124,4 +169,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])

@@ -27,11 +27,11 @@ def test_librtx_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     # 64-bit layout of include/rtx.h: catches a drifted ctypes mirror
     assert ctypes.sizeof(api.RtxParams) == 40
-    assert ctypes.sizeof(api.RtxHit) == 40
-    assert api.HIT_DTYPE.itemsize == 40
+    assert ctypes.sizeof(api.RtxHit) == 48
+    assert api.HIT_DTYPE.itemsize == 48
     assert ctypes.sizeof(api.RtxSceneInfo) == 16
     assert api.RtxScene.cam_origin.offset % 4 == 0
-    assert ctypes.sizeof(api.RtxScene) == 8 + 9 * 8 + 8 + 8 + 8 + 5 * 8 + 8 + 3 * 8 + 8 + 6 * 8 + 8 + 6 * 8 + 15 * 4 + 4
+    assert ctypes.sizeof(api.RtxScene) == 8 + 9 * 8 + 8 + 8 + 8 + 5 * 8 + 8 + 3 * 8 + 8 + 7 * 8 + 8 + 8 + 8 + 6 * 8 + 15 * 4 + 4
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback():

@@ -25,7 +25,7 @@ def test_restatement_reproduces_reference_samples(key, meta):
     assert np.array_equal(out["sum"], g["sum"], equal_nan=True)
 
 
-@pytest.mark.parametrize("name", ["cornell", "cornell_extra", "random_field", "bvh_stress_500"])
+@pytest.mark.parametrize("name", ["cornell", "cornell_extra", "random_field", "bvh_stress_500", "textured"])
 def test_restatement_reproduces_reference_hits(name):
     g = util.load_golden("hits_" + name)
     scene = api.HostScene(name, 32, 32)
@@ -33,7 +33,7 @@ def test_restatement_reproduces_reference_hits(name):
     assert np.array_equal(got["hit"], g["hit"].astype(np.int32))
     m = g["hit"] == 1
     assert m.sum() > 1000
-    for field in ("t", "p", "n"):
+    for field in ("t", "p", "n", "uv"):  # uv: Rect.cpp:27-28, Util.h:78-83
         assert np.array_equal(got[field][m], g[field][m]), field
     # material kind of the winner
     kinds = scene.arrays()["mat_kind"]
@@ -95,7 +95,8 @@ def test_builtin_scene_equals_transcribed_scene():
 
 @needs_ref
 def test_reference_and_restatement_agree_on_fresh_inputs():
-    for name, w, h, spp, seed in (("cornell_extra", 36, 20, 6, 1234), ("random_field", 30, 16, 3, 99)):
+    for name, w, h, spp, seed in (("cornell_extra", 36, 20, 6, 1234), ("random_field", 30, 16, 3, 99),
+                                  ("textured", 40, 22, 5, 31)):
         scene = api.HostScene(name, w, h)
         a = restate.render(scene, w, h, 10, spp, seed=seed, threads=4, per_sample=True)
         b = ref.RefScene(name, w, h).render(10, spp, seed=seed, threads=4, per_sample=True)

@@ -47,6 +47,8 @@ def _compare_samples(got_rgb, got_seg, want_rgb, want_seg):
     ("cornell_extra", 64, 36, 8, api.RTX_ACCEL_BVH),
     ("random_field", 48, 27, 4, api.RTX_ACCEL_BVH),
     ("bvh_stress_2000", 32, 18, 2, api.RTX_ACCEL_BVH),
+    ("textured", 64, 36, 8, api.RTX_ACCEL_LINEAR),
+    ("textured", 64, 36, 8, api.RTX_ACCEL_BVH),
 ])
 def test_deterministic_samples_match_reference(gpu_ctx, name, w, h, spp, accel):
     ref = _ref()
@@ -81,12 +83,13 @@ def test_hit_records_match_reference(gpu_ctx):
     ref = _ref()
     rng = np.random.default_rng(5)
     for name, accel in (("cornell", api.RTX_ACCEL_LINEAR), ("cornell_extra", api.RTX_ACCEL_BVH),
-                        ("random_field", api.RTX_ACCEL_LINEAR), ("random_field", api.RTX_ACCEL_BVH)):
+                        ("random_field", api.RTX_ACCEL_LINEAR), ("random_field", api.RTX_ACCEL_BVH),
+                        ("textured", api.RTX_ACCEL_LINEAR), ("textured", api.RTX_ACCEL_BVH)):
         scene = api.HostScene(name, 32, 32)
         gpu_ctx.upload(scene, accel)
         rs = ref.RefScene(name, 32, 32)
         n = 4096
-        if name.startswith("cornell"):
+        if name.startswith("cornell") or name == "textured":
             o = rng.uniform(1, 554, (n, 3)).astype(np.float32)
         else:
             o = rng.uniform(-8, 8, (n, 3)).astype(np.float32)
@@ -100,6 +103,7 @@ def test_hit_records_match_reference(gpu_ctx):
         assert np.array_equal(got["t"][m], want["t"][m])
         assert np.array_equal(got["p"][m], want["p"][m])
         assert np.array_equal(got["n"][m], want["n"][m])
+        assert np.array_equal(got["uv"][m], want["uv"][m])  # Rect.cpp:27-28, Util.h:78-83
 
 
 # ---------------------------------------------------------------------------
@@ -123,7 +127,7 @@ def test_deterministic_samples_match_golden(gpu_ctx, key, meta, accel):
     assert np.allclose(acc, g["sum"], rtol=2e-4, atol=1e-6, equal_nan=True)
 
 
-@pytest.mark.parametrize("name", ["cornell", "cornell_extra", "random_field", "bvh_stress_500"])
+@pytest.mark.parametrize("name", ["cornell", "cornell_extra", "random_field", "bvh_stress_500", "textured"])
 @pytest.mark.parametrize("accel", [api.RTX_ACCEL_LINEAR, api.RTX_ACCEL_BVH])
 def test_hit_records_match_golden(gpu_ctx, name, accel):
     g = util.load_golden("hits_" + name)
@@ -132,7 +136,7 @@ def test_hit_records_match_golden(gpu_ctx, name, accel):
     got = gpu_ctx.hit(g["origins"], g["directions"])
     assert np.array_equal(got["hit"], g["hit"].astype(np.int32))
     m = g["hit"] == 1
-    for field in ("t", "p", "n"):
+    for field in ("t", "p", "n", "uv"):
         assert np.array_equal(got[field][m], g[field][m]), field
     kinds = scene.arrays()["mat_kind"]
     assert np.array_equal(kinds[got["material"][m]].astype(np.int8), g["mat_kind"][m])
@@ -231,7 +235,7 @@ def test_device_resolve_matches_host_filter_chain(gpu_ctx):
     assert int(rays.item()) == host_rays
 
 
-@pytest.mark.parametrize("name", ["cornell", "cornell_extra", "random_field", "bvh_stress_500"])
+@pytest.mark.parametrize("name", ["cornell", "cornell_extra", "random_field", "bvh_stress_500", "textured"])
 @pytest.mark.parametrize("accel", [api.RTX_ACCEL_LINEAR, api.RTX_ACCEL_BVH])
 def test_fast_mode_hits_agree_with_golden_up_to_rounding(gpu_ctx, name, accel):
     """Fast mode re-orders the scan and fuses / approximates arithmetic: the same primitive
@@ -255,3 +259,25 @@ def test_fast_mode_hits_agree_with_golden_up_to_rounding(gpu_ctx, name, accel):
     # a sphere normal is (p - c) / r: the hit point's rounding error divided by a radius of 0.05-0.2
     assert np.abs(fast["n"][m] - det["n"][m]).max() < 5e-3
     assert np.array_equal(fast["material"][m], det["material"][m])
+    # texture coordinates: the sphere's wrap at phi = +-pi maps u = 0 onto u = 1
+    du = np.abs(fast["uv"][m] - det["uv"][m])
+    du[:, 0] = np.minimum(du[:, 0], 1.0 - du[:, 0])
+    assert du.max() < 5e-3
+
+
+def test_fast_mode_textured_scene_converges(gpu_ctx):
+    """Image textures in fast mode: same estimator as the CPU tracer on the same scene."""
+    from oracle import restate
+
+    w, h, spp = 96, 54, 128
+    scene = api.HostScene("textured", w, h)
+    cpu = restate.render(scene, w, h, 1000, 4 * spp, seed=5, threads=8)["sum"] / (4 * spp)
+    for accel in (api.RTX_ACCEL_LINEAR, api.RTX_ACCEL_BVH):
+        gpu_ctx.upload(scene, accel)
+        fast, _ = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_FAST, seed=9))
+        det, _ = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_DETERMINISTIC, seed=9))
+        gt = np.clip(cpu, 0, 1)
+        rmse_fast = np.sqrt(np.mean((np.clip(fast / spp, 0, 1) - gt) ** 2))
+        rmse_det = np.sqrt(np.mean((np.clip(det / spp, 0, 1) - gt) ** 2))
+        assert rmse_fast < 1.08 * rmse_det + 1e-4, (rmse_fast, rmse_det)
+        assert abs(np.clip(fast / spp, 0, 1).mean() - gt.mean()) < 0.004
