@@ -72,7 +72,7 @@ struct RtxContext {
     DeviceArray<rtxd::Light> lights;
     DeviceArray<rtxd::ScanGroup> scan_groups;
     DeviceArray<rtxd::ScanRec> scan_recs;
-    DeviceArray<rtxd::PrimInfo> scan_info;
+    DeviceArray<rtxd::ScanHit> scan_info;
     DeviceArray<uint32_t> scan_orig;
     DeviceArray<rtxd::BvhNode> bvh;
     DeviceArray<rtxd::Group> bvh_items;
@@ -191,7 +191,7 @@ void compose_chain(const std::vector<rtxd::Step>& steps, uint32_t begin, uint32_
 void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::PrimInfo>& info,
                       const std::vector<rtxd::Group>& groups, const std::vector<rtxd::Step>& steps,
                       std::vector<rtxd::ScanGroup>& sg, std::vector<rtxd::ScanRec>& sr,
-                      std::vector<rtxd::PrimInfo>& si, std::vector<uint32_t>& so) {
+                      std::vector<rtxd::ScanHit>& si, std::vector<uint32_t>& so) {
     for (uint32_t g = 0; g < groups.size(); ++g) {
         const rtxd::Group& G = groups[g];
         rtxd::ScanGroup S{};
@@ -207,10 +207,25 @@ void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rt
                 R.a = P.a; R.b = P.b; R.c = P.c; R.d = P.d;
                 R.e = kind == RTX_PRIM_SPHERE ? P.d * P.d : P.e;
                 sr.push_back(R);
-                rtxd::PrimInfo I = info[p];
-                I.step_begin = g;
-                I.step_end = S.identity ? g : g + 1u;
-                si.push_back(I);
+                const rtxd::PrimInfo& I = info[p];
+                rtxd::ScanHit H{};
+                H.r = I.r; H.g = I.g; H.b = I.b; H.param = I.param;
+                H.bits = I.bits; H.texture = I.texture;
+                H.group = g;
+                H.chained = S.identity ? 0u : 1u;
+                // group -> world: p_world = M^T (p_local - m)
+                const float sign = (P.kind_flip & 4u) ? -1.0f : 1.0f;
+                if (kind == RTX_PRIM_SPHERE) {
+                    const double l[3] = {(double)P.a - S.m[9], (double)P.b - S.m[10], (double)P.c - S.m[11]};
+                    for (int j = 0; j < 3; ++j)
+                        H.c[j] = (float)(S.m[0 + j] * l[0] + S.m[3 + j] * l[1] + S.m[6 + j] * l[2]);
+                    H.inv_r = sign / P.d;
+                } else {
+                    const int axis = kind == RTX_PRIM_RECT_XY ? 2 : (kind == RTX_PRIM_RECT_XZ ? 1 : 0);
+                    for (int j = 0; j < 3; ++j) H.n0[j] = sign * S.m[3 * axis + j];
+                    H.inv_r = 0.0f;
+                }
+                si.push_back(H);
                 so.push_back(p);
                 ++*counts[kind];
             }
@@ -376,7 +391,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     // bucketed table for the fast-mode linear scan
     std::vector<rtxd::ScanGroup> scan_groups;
     std::vector<rtxd::ScanRec> scan_recs;
-    std::vector<rtxd::PrimInfo> scan_info;
+    std::vector<rtxd::ScanHit> scan_info;
     std::vector<uint32_t> scan_orig;
     if (!use_bvh) build_scan_table(prims, info, groups, steps, scan_groups, scan_recs, scan_info, scan_orig);
     std::vector<rtxd::BvhNode> nodes;

@@ -434,46 +434,36 @@ RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, boo
     }
     if (best == kNone) return false;
 
-    // complete the record of the winner (per lane)
-    const PrimInfo I = sc.scan_info[best];
-    const ScanRec W = sc.scan_recs[best];
-    const uint32_t kind = I.bits & kInfoKindMask;
-    const bool chained = I.step_end != I.step_begin;
-    const bool uv = want_uv || (I.bits & kInfoNeedsUV);
+    // complete the record of the winner (per lane): one 64-byte record, no transform
+    const ScanHit I = sc.scan_info[best];
     const V3 p = o + d * closest;
-    float m[9];
-    if (chained) {
-        const ScanGroup* G = sc.scan_groups + I.step_begin;
-        for (int k = 0; k < 9; ++k) m[k] = G->m[k];
-    }
-    V3 pl = p;  // the hit point in the primitive's frame
-    if (chained && (kind == RTX_PRIM_SPHERE || uv)) {
-        const ScanGroup* G = sc.scan_groups + I.step_begin;
-        pl = v3(m[0] * p.x + m[1] * p.y + m[2] * p.z + G->m[9], m[3] * p.x + m[4] * p.y + m[5] * p.z + G->m[10],
-                m[6] * p.x + m[7] * p.y + m[8] * p.z + G->m[11]);
-    }
-    V3 n;
-    rec.u = rec.v = 0.0f;
-    if (kind == RTX_PRIM_SPHERE) {
-        n = (pl - v3(W.a, W.b, W.c)) * frcp(W.d);
-        if (uv) sphere_uv(n, rec.u, rec.v);
-    } else {
-        n = v3(kind == RTX_PRIM_RECT_YZ ? 1.0f : 0.0f, kind == RTX_PRIM_RECT_XZ ? 1.0f : 0.0f,
-               kind == RTX_PRIM_RECT_XY ? 1.0f : 0.0f);
-        if (uv) rect_uv(kind, W.a, W.b, W.c, W.d, pl, v3(0.0f, 0.0f, 0.0f), 0.0f, rec.u, rec.v);
-    }
-    if (I.bits & kInfoFlip) n = -n;
-    if (chained)  // back to world space: the transpose of the world->group rotation
-        n = v3(m[0] * n.x + m[3] * n.y + m[6] * n.z, m[1] * n.x + m[4] * n.y + m[7] * n.z,
-               m[2] * n.x + m[5] * n.y + m[8] * n.z);
+    const V3 pc = p - v3(I.c);
     rec.t = closest;
     rec.p = p;
-    rec.n = n;
+    rec.n = v3(__builtin_fmaf(pc.x, I.inv_r, I.n0[0]), __builtin_fmaf(pc.y, I.inv_r, I.n0[1]),
+               __builtin_fmaf(pc.z, I.inv_r, I.n0[2]));
     rec.prim = best;
     rec.bits = I.bits;
     rec.texture = I.texture;
     rec.param = I.param;
     rec.color = v3(I.r, I.g, I.b);
+    rec.u = rec.v = 0.0f;
+    if (want_uv || (I.bits & kInfoNeedsUV)) {  // texture coordinates live in the primitive's frame
+        const ScanRec W = sc.scan_recs[best];
+        const uint32_t kind = I.bits & kInfoKindMask;
+        V3 pl = p;
+        if (I.chained) {
+            const float* m = sc.scan_groups[I.group].m;
+            pl = v3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[9], m[3] * p.x + m[4] * p.y + m[5] * p.z + m[10],
+                    m[6] * p.x + m[7] * p.y + m[8] * p.z + m[11]);
+        }
+        if (kind == RTX_PRIM_SPHERE) {
+            V3 nl = (pl - v3(W.a, W.b, W.c)) * frcp(W.d);  // before FlipNormals (Sphere.cpp:19-21)
+            sphere_uv(nl, rec.u, rec.v);
+        } else {
+            rect_uv(kind, W.a, W.b, W.c, W.d, pl, v3(0.0f, 0.0f, 0.0f), 0.0f, rec.u, rec.v);
+        }
+    }
     return true;
 }
 // The fast linear scan reports positions of the bucketed table.
@@ -816,16 +806,23 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
     }
     if (mat_kind == RTX_MAT_METAL) {  // Metal.cpp:9-17
         V3 reflected = reflect(normalize(ps.d), rec.n);
-        V3 q;
-        do {  // random_in_unit_sphere, Util.h:32-38; runs even when fuzz == 0.
-            // The oracle build (g++) evaluates the three draws of random_vector()
-            // (Util.h:28-30) right to left: z, y, x.
-            float rz = rtx_rng_nextf(&ps.rng);
-            float ry = rtx_rng_nextf(&ps.rng);
-            float rx = rtx_rng_nextf(&ps.rng);
-            q = v3(rx, ry, rz) * 2.0f - v3(1.0f, 1.0f, 1.0f);
-        } while (length_sqr(q) >= 1.0f);
-        reflected = reflected + q * rec.param;
+#if !RTX_DET
+        // a perfect mirror ignores the fuzz vector; only the deterministic mode has to
+        // consume the reference's draws for it
+        if (rec.param != 0.0f)
+#endif
+        {
+            V3 q;
+            do {  // random_in_unit_sphere, Util.h:32-38; runs even when fuzz == 0.
+                // The oracle build (g++) evaluates the three draws of random_vector()
+                // (Util.h:28-30) right to left: z, y, x.
+                float rz = rtx_rng_nextf(&ps.rng);
+                float ry = rtx_rng_nextf(&ps.rng);
+                float rx = rtx_rng_nextf(&ps.rng);
+                q = v3(rx, ry, rz) * 2.0f - v3(1.0f, 1.0f, 1.0f);
+            } while (length_sqr(q) >= 1.0f);
+            reflected = reflected + q * rec.param;
+        }
         V3 albedo = surface_color(sc, rec);
         if (!(dot(reflected, rec.n) > 0.0f)) return true;
         ps.T = vmul(albedo, ps.T);  // Scene.cpp:110

@@ -53,6 +53,21 @@ struct alignas(16) ScanGroup {
     uint32_t pad[2];
 };
 
+// What completing a fast-mode scan hit needs, in world space, so that no transform is applied
+// per hit: n = (p - c) * inv_r + n0 covers both kinds (rect: inv_r = 0, n0 = the rect's
+// normal taken through the group's rotation, FlipNormals parity applied; sphere: c = centre
+// in world space, inv_r = +-1 / radius, n0 = 0).  Rotations and translations keep lengths,
+// so (p - c) / r is the same vector whether it is formed in the group's frame and rotated
+// out (Sphere.cpp:19, Rotate.cpp:13) or formed in world space.
+struct alignas(64) ScanHit {
+    float r, g, b, param;  // as PrimInfo
+    uint32_t bits, texture;
+    uint32_t group;        // scan group (its affine map is only needed for texture coordinates)
+    uint32_t chained;      // 1: the group has a transform
+    float n0[3], inv_r;
+    float c[3], pad;
+};
+
 // A run of consecutive primitives that share one transform chain.
 struct alignas(16) Group {
     uint32_t prim_begin, prim_end;
@@ -114,7 +129,7 @@ struct SceneView {
     // bucketed copy for the fast-mode linear scan (null when a BVH is used)
     const ScanGroup* scan_groups;
     const ScanRec* scan_recs;      // n_prims + 1 records
-    const PrimInfo* scan_info;     // in scan order; step_begin = scan group, step_end = 1 if transformed
+    const ScanHit* scan_info;      // in scan order
     const uint32_t* scan_orig;     // scan position -> original primitive index
     uint32_t n_scan_groups;
     uint32_t scan_pad_;
