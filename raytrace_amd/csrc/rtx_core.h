@@ -126,6 +126,33 @@ RTX_DEV T load_uniform(const T* base, uint32_t i) {
     return base[(uint32_t)__builtin_amdgcn_readfirstlane(i)];
 }
 
+// ---------------------------------------------------------------------------
+// random stream
+// ---------------------------------------------------------------------------
+#if RTX_DET
+// the stream every party of a parity test shares (include/rtx_det.h)
+RTX_DEV void rng_init(RtxRng* r, uint32_t pixel, uint32_t sample, uint64_t seed) { rtx_rng_init(r, pixel, sample, seed); }
+RTX_DEV float rng_nextf(RtxRng* r) { return rtx_rng_nextf(r); }
+#else
+// Fast mode only has to be statistically equal, and the shared stream is a sizeable part of
+// the kernel's issue cycles (two 32-bit multiplies, a variable shift and an int->float
+// conversion per draw, six hashes per sample).  Same structure - a 32-bit LCG per (pixel,
+// absolute sample index, seed) whose odd increment selects the stream - but keyed with two
+// hashes and read out as the top 23 bits of the state placed in the mantissa of [1, 2).
+RTX_DEV void rng_init(RtxRng* r, uint32_t pixel, uint32_t sample, uint64_t seed) {
+    const uint32_t k = rtx_hash32((uint32_t)seed ^ rtx_hash32((uint32_t)(seed >> 32) ^ 0x9e3779b9u));  // wave-uniform
+    const uint32_t a = rtx_hash32(pixel ^ k);
+    const uint32_t b = rtx_hash32(sample ^ a);
+    r->state = b;
+    r->inc = (a << 1) | 1u;
+}
+RTX_DEV float rng_nextf(RtxRng* r) {
+    const uint32_t s = r->state * 747796405u + r->inc;
+    r->state = s;
+    return __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, s, 9u)) - 1.0f;  // 0x3f800000 | (s >> 9)
+}
+#endif
+
 struct HitRec {
     float t;
     V3 p, n;
@@ -656,10 +683,10 @@ RTX_DEV V3 sample_direction(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
     uint32_t kind = kSampleCosine;
     Light E;
     E.a = E.b = E.c = E.d = E.e = 0.0f;
-    if (rtx_rng_nextf(&rng) < 0.5f) {
+    if (rng_nextf(&rng) < 0.5f) {
         uint32_t index = 0;
         if (sc.light_is_list) {
-            float r = rtx_rng_nextf(&rng);
+            float r = rng_nextf(&rng);
             index = (uint32_t)(r * (float)sc.n_lights);
             if (index >= sc.n_lights) index = sc.n_lights - 1;
         }
@@ -669,8 +696,8 @@ RTX_DEV V3 sample_direction(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
     const bool is_sphere = kind == RTX_LIGHT_SPHERE;
     const bool is_rect = kind == RTX_LIGHT_RECT_XZ;
     if (!(is_sphere | is_rect | (kind == kSampleCosine))) return v3(1.0f, 0.0f, 0.0f);
-    const float r1 = rtx_rng_nextf(&rng);
-    const float r2 = rtx_rng_nextf(&rng);
+    const float r1 = rng_nextf(&rng);
+    const float r2 = rng_nextf(&rng);
     if (is_rect) {
         float x = E.a + r1 * (E.b - E.a);
         float y = E.c + r2 * (E.d - E.c);
@@ -816,9 +843,9 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
             do {  // random_in_unit_sphere, Util.h:32-38; runs even when fuzz == 0.
                 // The oracle build (g++) evaluates the three draws of random_vector()
                 // (Util.h:28-30) right to left: z, y, x.
-                float rz = rtx_rng_nextf(&ps.rng);
-                float ry = rtx_rng_nextf(&ps.rng);
-                float rx = rtx_rng_nextf(&ps.rng);
+                float rz = rng_nextf(&ps.rng);
+                float ry = rng_nextf(&ps.rng);
+                float rx = rng_nextf(&ps.rng);
                 q = v3(rx, ry, rz) * 2.0f - v3(1.0f, 1.0f, 1.0f);
             } while (length_sqr(q) >= 1.0f);
             reflected = reflected + q * rec.param;
@@ -850,7 +877,7 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
         V3 refracted = v3(0.0f, 0.0f, 0.0f);
         float reflect_prob = 1.0f;
         if (refract(-ps.d, outward, ni_over_nt, refracted)) reflect_prob = schlick(cosine, ri);
-        V3 dir = (rtx_rng_nextf(&ps.rng) < reflect_prob) ? reflected : refracted;
+        V3 dir = (rng_nextf(&ps.rng) < reflect_prob) ? reflected : refracted;
         // albedo is (1,1,1): the weight is unchanged (mulPerElem by one is exact)
         ps.o = rec.p;
         ps.d = dir;
@@ -877,6 +904,10 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
 template <bool kBvh, bool kSamples>
 __global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES) trace_kernel(const TraceArgs a) {
     __shared__ float s_acc[RTX_BLOCK / 64][3][64];
+#ifdef RTX_PROBE_LDS_BYTES  // occupancy experiments: LDS ballast that caps the resident blocks per CU
+    __shared__ float s_ballast[RTX_PROBE_LDS_BYTES / 4];
+    if (a.width == 0xffffffffu) s_ballast[threadIdx.x] = 1.0f;
+#endif
     const SceneView& sc = a.scene;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -916,9 +947,9 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES) trace_kernel(const
                 if (sx < tw && sy < th) {
                     item = mine;
                     const uint32_t i = x0 + sx, j = y0 + sy;
-                    rtx_rng_init(&ps.rng, j * a.width + i, a.spp_begin + (mine >> 6), a.seed);
-                    float u = fdiv((float)i + rtx_rng_nextf(&ps.rng), fnx);  // Scene.cpp:145-146
-                    float v = fdiv((float)j + rtx_rng_nextf(&ps.rng), fny);
+                    rng_init(&ps.rng, j * a.width + i, a.spp_begin + (mine >> 6), a.seed);
+                    float u = fdiv((float)i + rng_nextf(&ps.rng), fnx);  // Scene.cpp:145-146
+                    float v = fdiv((float)j + rng_nextf(&ps.rng), fny);
                     // Camera::getRay, Camera.h:24-26
                     ps.o = v3(sc.cam_origin);
                     ps.d = ((v3(sc.cam_ll) + v3(sc.cam_u) * u) + v3(sc.cam_v) * v) - ps.o;
