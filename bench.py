@@ -30,10 +30,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# MI355X FP32 vector peak: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz = 157.3 TFLOP/s with
-# packed FP32 (v_pk_fma_f32); 78.6 TFLOP/s for non-packed v_fma_f32.
+# MI355X FP32 vector peak: 256 CU x 4 SIMD x 32 FMA lanes x 2 flops x 2.4 GHz = 157.3 TFLOP/s.
+# Measured on the part (tools/probe/valu_cost.hip): a wave64 v_fma_f32 with VGPR operands issues
+# every ~2.5 cycles and a v_pk_fma_f32 every ~4.5, so plain and packed FMAs reach the same rate.
 PEAK_FP32_VALU_TFLOPS = 157.3
-PEAK_FP32_VALU_NONPACKED_TFLOPS = 78.6
 
 WORKLOADS = {
     # name: (scene, width, height, default spp per step)
@@ -78,9 +78,9 @@ def cpu_baseline(scene: str, w: int, h: int, threads: int, seconds_budget: float
         kind = "reference"
         rs = ref.RefScene(scene, w, h)
 
-        def run(spp):
+        def run(spp, n_threads=threads):
             t = time.perf_counter()
-            out = rs.render(0, spp, seed=0, threads=threads)
+            out = rs.render(0, spp, seed=0, threads=n_threads)
             return time.perf_counter() - t, out["rays"]
     else:
         from oracle import restate
@@ -91,14 +91,15 @@ def cpu_baseline(scene: str, w: int, h: int, threads: int, seconds_budget: float
 
         flat = api.HostScene(scene, w, h)
 
-        def run(spp):
+        def run(spp, n_threads=threads):
             t = time.perf_counter()
-            out = restate.render(flat, w, h, 0, spp, seed=0, threads=threads)
+            out = restate.render(flat, w, h, 0, spp, seed=0, threads=n_threads)
             return time.perf_counter() - t, out["rays"]
 
     dt1, rays1 = run(1)
     spp = int(max(1, min(64, seconds_budget / max(dt1, 1e-3))))
     dt, rays = (dt1, rays1) if spp == 1 else run(spp)
+    dts, rays_s = run(1, 1)  # one sample per pixel on one core
     return {
         "value": rays / dt / 1e6,
         "unit": "Mrays/s",
@@ -106,6 +107,8 @@ def cpu_baseline(scene: str, w: int, h: int, threads: int, seconds_budget: float
         "kind": kind,
         "sample": f"{scene} {w}x{h}, {spp} spp, depth 50, deterministic stream, {dt:.1f} s",
         "spp_per_s": spp / dt,
+        "single_core_value": rays_s / dts / 1e6,
+        "single_core_sample": f"1 spp, {dts:.1f} s",
     }
 
 
@@ -203,9 +206,13 @@ def main() -> int:
     if rank == 0:
         samples = w * h * spp * world * args.steps
         flops_per_ray, flops_src = load_flops_per_ray(scene_name)
+        if info.accel == api.RTX_ACCEL_BVH:
+            # the counted figure is the reference's O(N) scan; the tree's own traversal is not
+            # op-counted, so no flop rate is claimed for these workloads
+            flops_per_ray, flops_src = None, "not counted for BVH traversal"
         avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
         rays_per_launch = my_rays / args.steps
-        achieved_tflops = flops_per_ray * rays_per_launch / avg_kernel_s / 1e12
+        achieved_tflops = None if flops_per_ray is None else flops_per_ray * rays_per_launch / avg_kernel_s / 1e12
         out = {
             "metric": "Mrays/s at 1080p Cornell box (whole job)" if args.workload == "cornell_1080p"
                       else f"Mrays/s ({args.workload})",
@@ -239,8 +246,7 @@ def main() -> int:
                 "achieved": achieved_tflops,
                 "peak": PEAK_FP32_VALU_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS,
-                "frac_of_nonpacked_peak": achieved_tflops / PEAK_FP32_VALU_NONPACKED_TFLOPS,
+                "frac": None if achieved_tflops is None else achieved_tflops / PEAK_FP32_VALU_TFLOPS,
                 "traffic": load_hbm_traffic(args.workload, spp),
                 "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/hbm_traffic.json)",
                 "kernel": "trace_kernel",

@@ -405,17 +405,42 @@ RTX_DEV uint32_t original_prim(const SceneView&, uint32_t prim, bool) { return p
 #else
 // Fast mode: the bucketed table (ScanGroup / ScanRec): per group one composed affine map and
 // four homogeneous loops (XY, XZ, YZ rects, spheres) whose bodies are branch-free.
+// One rect of the bucketed table against every lane's ray.  The six interval tests are
+// v_cmpx instructions: each one clears the lanes that fail from EXEC, so no mask has to be
+// combined on the scalar unit and the two updates are plain moves under the surviving lanes.
+template <int XI, int YI, int ZI>
+RTX_DEV void scan_rect(const ScanRec& R, uint32_t pos, V3 ro, V3 rd, const RayAux& aux, float t0, float& closest,
+                       uint32_t& best) {
+    float t, x, y;
+    unsigned long long saved;
+    // not volatile: the statement touches no memory, and a volatile one would stop the
+    // compiler from proving the record loads around it uniform and read-only (scalar loads)
+    asm("v_fma_f32 %[t], %[k], %[inv], %[noi]\n\t"
+        "v_fma_f32 %[x], %[t], %[dx], %[ox]\n\t"
+        "v_fma_f32 %[y], %[t], %[dy], %[oy]\n\t"
+        "s_mov_b64 %[saved], exec\n\t"
+        "v_cmpx_le_f32 vcc, %[t0], %[t]\n\t"
+        "v_cmpx_ge_f32 vcc, %[closest], %[t]\n\t"
+        "v_cmpx_le_f32 vcc, %[x0], %[x]\n\t"
+        "v_cmpx_ge_f32 vcc, %[x1], %[x]\n\t"
+        "v_cmpx_le_f32 vcc, %[y0], %[y]\n\t"
+        "v_cmpx_ge_f32 vcc, %[y1], %[y]\n\t"
+        "v_mov_b32 %[closest], %[t]\n\t"
+        "v_mov_b32 %[best], %[pos]\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [t] "=&v"(t), [x] "=&v"(x), [y] "=&v"(y), [saved] "=&s"(saved), [closest] "+v"(closest), [best] "+v"(best)
+        : [k] "s"(R.e), [inv] "v"(comp<ZI>(aux.inv_d)), [noi] "v"(comp<ZI>(aux.noi)), [dx] "v"(comp<XI>(rd)),
+          [ox] "v"(comp<XI>(ro)), [dy] "v"(comp<YI>(rd)), [oy] "v"(comp<YI>(ro)), [t0] "s"(t0), [x0] "s"(R.a),
+          [x1] "s"(R.b), [y0] "s"(R.c), [y1] "s"(R.d), [pos] "s"(pos)
+        : "vcc");
+}
+
 template <int XI, int YI, int ZI>
 RTX_DEV void scan_rects(const SceneView& sc, uint32_t& pos, uint32_t count, V3 ro, V3 rd, const RayAux& aux,
                         float t0, float& closest, uint32_t& best) {
     for (uint32_t k = 0; k < count; ++k, ++pos) {
         const ScanRec R = load_uniform(sc.scan_recs, pos);
-        float t = __builtin_fmaf(R.e, comp<ZI>(aux.inv_d), comp<ZI>(aux.noi));
-        float x = __builtin_fmaf(t, comp<XI>(rd), comp<XI>(ro));
-        float y = __builtin_fmaf(t, comp<YI>(rd), comp<YI>(ro));
-        bool ok = (t >= t0) & (t <= closest) & (x >= R.a) & (x <= R.b) & (y >= R.c) & (y <= R.d);
-        closest = ok ? t : closest;
-        best = ok ? pos : best;
+        scan_rect<XI, YI, ZI>(R, pos, ro, rd, aux, t0, closest, best);
     }
 }
 
