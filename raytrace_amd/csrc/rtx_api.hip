@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "rtx.h"
@@ -188,47 +189,109 @@ void compose_chain(const std::vector<rtxd::Step>& steps, uint32_t begin, uint32_
     }
 }
 
+// The ScanHit of one primitive of group g (world->group map S.m).
+rtxd::ScanHit make_scan_hit(const rtxd::Prim& P, const rtxd::PrimInfo& I, const rtxd::ScanGroup& S, uint32_t g) {
+    rtxd::ScanHit H{};
+    H.r = I.r; H.g = I.g; H.b = I.b; H.param = I.param;
+    H.bits = I.bits; H.texture = I.texture;
+    H.group = g;
+    H.chained = S.identity ? 0u : 1u;
+    // group -> world: p_world = M^T (p_local - m)
+    const uint32_t kind = P.kind_flip & 3u;
+    const float sign = (P.kind_flip & 4u) ? -1.0f : 1.0f;
+    if (kind == RTX_PRIM_SPHERE) {
+        const double l[3] = {(double)P.a - S.m[9], (double)P.b - S.m[10], (double)P.c - S.m[11]};
+        for (int j = 0; j < 3; ++j) H.c[j] = (float)(S.m[0 + j] * l[0] + S.m[3 + j] * l[1] + S.m[6 + j] * l[2]);
+        H.inv_r = sign / P.d;
+    } else {
+        const int axis = kind == RTX_PRIM_RECT_XY ? 2 : (kind == RTX_PRIM_RECT_XZ ? 1 : 0);
+        for (int j = 0; j < 3; ++j) H.n0[j] = sign * S.m[3 * axis + j];
+        H.inv_r = 0.0f;
+    }
+    return H;
+}
+
+// Rects of [begin, end) that are the six complete faces of one axis-aligned box: returns the
+// boxes as primitive indices in face order +z, -z, +y, -y, +x, -x and marks them used.
+std::vector<std::array<uint32_t, 6>> find_boxes(const std::vector<rtxd::Prim>& prims, uint32_t begin, uint32_t end,
+                                                 std::vector<char>& used) {
+    std::vector<std::array<uint32_t, 6>> boxes;
+    auto kind = [&](uint32_t p) { return prims[p].kind_flip & 3u; };
+    auto face = [&](uint32_t want_kind, float x0, float x1, float y0, float y1, float k) -> int {
+        for (uint32_t p = begin; p < end; ++p) {
+            const rtxd::Prim& P = prims[p];
+            if (!used[p] && kind(p) == want_kind && P.a == x0 && P.b == x1 && P.c == y0 && P.d == y1 && P.e == k)
+                return (int)p;
+        }
+        return -1;
+    };
+    for (uint32_t p = begin; p < end; ++p) {
+        if (used[p] || kind(p) != RTX_PRIM_RECT_XY) continue;
+        for (uint32_t q = p + 1; q < end; ++q) {
+            if (used[q] || kind(q) != RTX_PRIM_RECT_XY) continue;
+            const rtxd::Prim &A = prims[p], &B = prims[q];
+            if (A.a != B.a || A.b != B.b || A.c != B.c || A.d != B.d || A.e == B.e) continue;
+            if (!(A.a < A.b) || !(A.c < A.d)) continue;
+            const float X0 = A.a, X1 = A.b, Y0 = A.c, Y1 = A.d, Z0 = std::min(A.e, B.e), Z1 = std::max(A.e, B.e);
+            used[p] = used[q] = 1;  // so that face() skips them
+            const int zh = A.e == Z1 ? (int)p : (int)q, zl = A.e == Z1 ? (int)q : (int)p;
+            const int yh = face(RTX_PRIM_RECT_XZ, X0, X1, Z0, Z1, Y1);
+            if (yh >= 0) used[yh] = 1;
+            const int yl = face(RTX_PRIM_RECT_XZ, X0, X1, Z0, Z1, Y0);
+            if (yl >= 0) used[yl] = 1;
+            const int xh = face(RTX_PRIM_RECT_YZ, Y0, Y1, Z0, Z1, X1);
+            if (xh >= 0) used[xh] = 1;
+            const int xl = face(RTX_PRIM_RECT_YZ, Y0, Y1, Z0, Z1, X0);
+            if (xl >= 0) used[xl] = 1;
+            if (yh >= 0 && yl >= 0 && xh >= 0 && xl >= 0) {
+                boxes.push_back({(uint32_t)zh, (uint32_t)zl, (uint32_t)yh, (uint32_t)yl, (uint32_t)xh, (uint32_t)xl});
+                break;
+            }
+            for (int f : {(int)p, (int)q, yh, yl, xh, xl})
+                if (f >= 0) used[f] = 0;
+        }
+    }
+    return boxes;
+}
+
 void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::PrimInfo>& info,
                       const std::vector<rtxd::Group>& groups, const std::vector<rtxd::Step>& steps,
                       std::vector<rtxd::ScanGroup>& sg, std::vector<rtxd::ScanRec>& sr,
                       std::vector<rtxd::ScanHit>& si, std::vector<uint32_t>& so) {
+    std::vector<char> used(prims.size(), 0);
     for (uint32_t g = 0; g < groups.size(); ++g) {
         const rtxd::Group& G = groups[g];
         rtxd::ScanGroup S{};
         compose_chain(steps, G.step_begin, G.step_end, S.m);
         S.identity = G.step_end == G.step_begin ? 1u : 0u;
         S.first = (uint32_t)sr.size();
+        const auto boxes = find_boxes(prims, G.prim_begin, G.prim_end, used);
         uint32_t* counts[4] = {&S.n_xy, &S.n_xz, &S.n_yz, &S.n_sph};
         for (uint32_t kind = 0; kind < 4; ++kind) {
             for (uint32_t p = G.prim_begin; p < G.prim_end; ++p) {
                 const rtxd::Prim& P = prims[p];
-                if ((P.kind_flip & 3u) != kind) continue;
+                if (used[p] || (P.kind_flip & 3u) != kind) continue;
                 rtxd::ScanRec R{};
                 R.a = P.a; R.b = P.b; R.c = P.c; R.d = P.d;
                 R.e = kind == RTX_PRIM_SPHERE ? P.d * P.d : P.e;
                 sr.push_back(R);
-                const rtxd::PrimInfo& I = info[p];
-                rtxd::ScanHit H{};
-                H.r = I.r; H.g = I.g; H.b = I.b; H.param = I.param;
-                H.bits = I.bits; H.texture = I.texture;
-                H.group = g;
-                H.chained = S.identity ? 0u : 1u;
-                // group -> world: p_world = M^T (p_local - m)
-                const float sign = (P.kind_flip & 4u) ? -1.0f : 1.0f;
-                if (kind == RTX_PRIM_SPHERE) {
-                    const double l[3] = {(double)P.a - S.m[9], (double)P.b - S.m[10], (double)P.c - S.m[11]};
-                    for (int j = 0; j < 3; ++j)
-                        H.c[j] = (float)(S.m[0 + j] * l[0] + S.m[3 + j] * l[1] + S.m[6 + j] * l[2]);
-                    H.inv_r = sign / P.d;
-                } else {
-                    const int axis = kind == RTX_PRIM_RECT_XY ? 2 : (kind == RTX_PRIM_RECT_XZ ? 1 : 0);
-                    for (int j = 0; j < 3; ++j) H.n0[j] = sign * S.m[3 * axis + j];
-                    H.inv_r = 0.0f;
-                }
-                si.push_back(H);
+                si.push_back(make_scan_hit(P, info[p], S, g));
                 so.push_back(p);
                 ++*counts[kind];
             }
+        }
+        for (const auto& box : boxes) {
+            const rtxd::Prim &ZH = prims[box[0]], &ZL = prims[box[1]], &YH = prims[box[2]], &YL = prims[box[3]];
+            rtxd::ScanRec R{};
+            R.a = ZH.a; R.b = ZH.c; R.c = ZL.e;  // lo
+            R.d = ZH.b; R.e = ZH.d; R.f = ZH.e;  // hi
+            (void)YH; (void)YL;
+            for (uint32_t f = 0; f < rtxd::kBoxSlots; ++f) {
+                sr.push_back(f == 0 ? R : rtxd::ScanRec{});
+                si.push_back(make_scan_hit(prims[box[f]], info[box[f]], S, g));
+                so.push_back(box[f]);
+            }
+            ++S.n_box;
         }
         sg.push_back(S);
     }

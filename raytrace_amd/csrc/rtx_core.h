@@ -444,6 +444,45 @@ RTX_DEV void scan_rects(const SceneView& sc, uint32_t& pos, uint32_t count, V3 r
     }
 }
 
+// Complete boxes (six rects that are the faces of one axis-aligned box, Box.cpp:11-29) by a
+// slab test: the ray meets the planes of axis a at tl_a, th_a; it is inside all three slabs
+// for t in [max near_a, min far_a].  Of a closed convex box it can only hit the face it
+// enters through or, when that lies behind t0 (origin inside or on the box), the face it
+// leaves through; each rect's own t is the same fma as in scan_rect, its bounds tests are
+// implied by the other two slabs.  The face is recovered from which slab produced t.
+RTX_DEV void scan_boxes(const SceneView& sc, uint32_t& pos, uint32_t count, V3 ro, const RayAux& aux, float t0,
+                        float& closest, uint32_t& best) {
+    // a direction component of exactly zero makes inv_d infinite and k * inv_d + noi NaN, which
+    // min / max would silently drop: keep the reciprocal finite, then a parallel ray is inside
+    // the slab for all t or for none
+    constexpr float kBig = 1.0e30f;
+    const V3 inv = v3(__builtin_amdgcn_fmed3f(aux.inv_d.x, -kBig, kBig), __builtin_amdgcn_fmed3f(aux.inv_d.y, -kBig, kBig),
+                      __builtin_amdgcn_fmed3f(aux.inv_d.z, -kBig, kBig));
+    const V3 noi = v3(-ro.x * inv.x, -ro.y * inv.y, -ro.z * inv.z);
+    for (uint32_t k = 0; k < count; ++k, pos += kBoxSlots) {
+        const ScanRec R = load_uniform(sc.scan_recs, pos);
+        const float lx = __builtin_fmaf(R.a, inv.x, noi.x), hx = __builtin_fmaf(R.d, inv.x, noi.x);
+        const float ly = __builtin_fmaf(R.b, inv.y, noi.y), hy = __builtin_fmaf(R.e, inv.y, noi.y);
+        const float lz = __builtin_fmaf(R.c, inv.z, noi.z), hz = __builtin_fmaf(R.f, inv.z, noi.z);
+        const bool px = lx < hx, py = ly < hy, pz = lz < hz;  // travelling towards + along the axis
+        const float nx = px ? lx : hx, fx = px ? hx : lx;
+        const float ny = py ? ly : hy, fy = py ? hy : ly;
+        const float nz = pz ? lz : hz, fz = pz ? hz : lz;
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+        const float tf = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+        const bool enter = tn >= t0;
+        const float t = enter ? tn : tf;
+        const bool ok = (tn <= tf) & (t >= t0) & (t <= closest);
+        const float cx = enter ? nx : fx, cy = enter ? ny : fy;
+        const bool ax = cx == t, ay = cy == t;
+        uint32_t face = ax ? 4u : (ay ? 2u : 0u);
+        const bool towards_plus = ax ? px : (ay ? py : pz);
+        face += (enter == towards_plus) ? 1u : 0u;  // the low face: entered when travelling towards +, left when towards -
+        closest = ok ? t : closest;
+        best = ok ? pos + face : best;
+    }
+}
+
 RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool want_uv, HitRec& rec) {
     float closest = t1;
     uint32_t best = kNone;
@@ -483,6 +522,7 @@ RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, boo
                 best = ok ? pos : best;
             }
         }
+        if (G.n_box) scan_boxes(sc, pos, G.n_box, ro, aux, t0, closest, best);
     }
     if (best == kNone) return false;
 
@@ -501,7 +541,7 @@ RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, boo
     rec.color = v3(I.r, I.g, I.b);
     rec.u = rec.v = 0.0f;
     if (want_uv || (I.bits & kInfoNeedsUV)) {  // texture coordinates live in the primitive's frame
-        const ScanRec W = sc.scan_recs[best];
+        const Prim W = sc.prims[sc.scan_orig[best]];  // the table position of a box face holds no rect
         const uint32_t kind = I.bits & kInfoKindMask;
         V3 pl = p;
         if (I.chained) {

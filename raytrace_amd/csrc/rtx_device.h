@@ -40,18 +40,24 @@ constexpr uint32_t kInfoNeedsUV = 64u;       // ... and it (or a sub-texture) is
 // YZ rects, spheres) so that each kind is scanned by a branch-free loop over homogeneous
 // 32-byte records fetched with one scalar load each.
 struct alignas(32) ScanRec {
-    float a, b, c, d, e;  // rect: x0 x1 y0 y1 k | sphere: cx cy cz r r*r
-    uint32_t pad[3];
+    float a, b, c, d, e, f;  // rect: x0 x1 y0 y1 k | sphere: cx cy cz r r*r | box: lo xyz, hi xyz
+    uint32_t pad[2];
 };
 // One group of the bucketed table: the composed world->group affine map (rows of the 3x3
 // matrix then the offset) instead of the un-composed step chain, and the kind counts.
+// Six rects of a group that are the complete faces of one axis-aligned box (what Box.cpp:11-29
+// builds) are scanned as ONE record by a slab test.  A box owns six consecutive positions of
+// the table - the record itself, then five unused ones - so that position + face (0..5 = +z,
+// -z, +y, -y, +x, -x, the order of Box.cpp:15-28) still names one ScanHit / original primitive.
 struct alignas(16) ScanGroup {
     float m[12];           // p_local = (m[0..2].p + m[9], m[3..5].p + m[10], m[6..8].p + m[11])
     uint32_t first;        // index of the group's first ScanRec
     uint32_t n_xy, n_xz, n_yz, n_sph;
     uint32_t identity;     // 1: no transform
-    uint32_t pad[2];
+    uint32_t n_box;
+    uint32_t pad;
 };
+constexpr uint32_t kBoxSlots = 6;
 
 // What completing a fast-mode scan hit needs, in world space, so that no transform is applied
 // per hit: n = (p - c) * inv_r + n0 covers both kinds (rect: inv_r = 0, n0 = the rect's
@@ -128,7 +134,7 @@ struct SceneView {
     const Light* lights;
     // bucketed copy for the fast-mode linear scan (null when a BVH is used)
     const ScanGroup* scan_groups;
-    const ScanRec* scan_recs;      // n_prims + 1 records
+    const ScanRec* scan_recs;      // one per scan position + 1 readable pad record
     const ScanHit* scan_info;      // in scan order
     const uint32_t* scan_orig;     // scan position -> original primitive index
     uint32_t n_scan_groups;
