@@ -957,13 +957,14 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
 
 // The loops of Scene::render (Scene.cpp:140-149) around the integrator.
 //
-// Work distribution.  A wave owns an 8x8 pixel tile (2x2 waves per 256-thread block) and the
-// pool of its (pixel, sample) items: item k is pixel slot k & 63 of the tile, sample
-// spp_begin + (k >> 6).  A lane whose path has ended draws the next item of the pool
+// Work distribution.  A wave owns a tile of P = 4 .. 64 pixels (2x2 .. 8x8, chosen by the
+// launcher from the sample count; 2x2 waves per 256-thread block) and the pool of its
+// (pixel, sample) items: item k is pixel slot k mod P of the tile, sample
+// spp_begin + k / P.  A lane whose path has ended draws the next item of the pool
 // (wave64 ballot + prefix count), so every lane runs the nearest-hit query each iteration
 // until the pool is empty, whatever the path lengths of the individual pixels.  A finished
-// sample is added to its pixel's sum in LDS (one fp32 add per channel); lane l writes pixel
-// slot l to HBM once, at the end.  Only this wave touches its slice of LDS, and the wave
+// sample is added to its pixel's sum in LDS (one fp32 add per channel); lane l < P writes
+// pixel slot l to HBM once, at the end.  Only this wave touches its slice of LDS, and the wave
 // executes in lockstep, so the order of the adds - and with it every bit of the result -
 // is reproducible from run to run.
 template <bool kBvh, bool kSamples>
@@ -976,19 +977,20 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES) trace_kernel(const
     const SceneView& sc = a.scene;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr uint32_t kTile = RTX_BLOCK == 256 ? 16u : 8u;  // pixels per block edge
-    const uint32_t tiles_x = (a.width + kTile - 1u) / kTile;
+    const uint32_t twl = a.tile_w_log2, pixl = a.tile_w_log2 + a.tile_h_log2;  // this wave's pixel tile
+    const uint32_t tile_w = 1u << twl, tile_h = 1u << a.tile_h_log2, pix_mask = (1u << pixl) - 1u;
+    const uint32_t tiles_x = (a.width + 2u * tile_w - 1u) / (2u * tile_w);
     const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
-    const uint32_t x0 = bx * kTile + (wave & 1u) * 8u;  // tile origin; rows counted from the bottom
-    const uint32_t y0 = by * kTile + (wave >> 1) * 8u;
+    const uint32_t x0 = (2u * bx + (wave & 1u)) * tile_w;  // tile origin; rows counted from the bottom
+    const uint32_t y0 = (2u * by + (wave >> 1)) * tile_h;
     if (x0 >= a.width || y0 >= a.height) return;  // wave-uniform
-    const uint32_t tw = min(8u, a.width - x0), th = min(8u, a.height - y0);
+    const uint32_t tw = min(tile_w, a.width - x0), th = min(tile_h, a.height - y0);
 
     s_acc[wave][0][lane] = 0.0f;
     s_acc[wave][1][lane] = 0.0f;
     s_acc[wave][2][lane] = 0.0f;
 
-    const uint32_t total = 64u * a.spp_count;  // items of this wave's pool
+    const uint32_t total = a.spp_count << pixl;  // items of this wave's pool
     uint32_t next = 0;                         // wave-uniform pool cursor
     uint32_t rays = 0, segs = 0, item = 0;
     bool active = false;
@@ -1007,12 +1009,12 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES) trace_kernel(const
             const uint32_t mine = next + rank;
             next += (uint32_t)__popcll(want);
             if (!active && mine < total) {
-                const uint32_t slot = mine & 63u;
-                const uint32_t sx = slot & 7u, sy = slot >> 3;
+                const uint32_t slot = mine & pix_mask;
+                const uint32_t sx = slot & (tile_w - 1u), sy = slot >> twl;
                 if (sx < tw && sy < th) {
                     item = mine;
                     const uint32_t i = x0 + sx, j = y0 + sy;
-                    rng_init(&ps.rng, j * a.width + i, a.spp_begin + (mine >> 6), a.seed);
+                    rng_init(&ps.rng, j * a.width + i, a.spp_begin + (mine >> pixl), a.seed);
                     float u = fdiv((float)i + rng_nextf(&ps.rng), fnx);  // Scene.cpp:145-146
                     float v = fdiv((float)j + rng_nextf(&ps.rng), fny);
                     // Camera::getRay, Camera.h:24-26
@@ -1035,14 +1037,14 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES) trace_kernel(const
             ++segs;
             V3 L;
             if (shade(sc, a.max_depth, hit, rec, ps, L)) {
-                const uint32_t slot = item & 63u;
+                const uint32_t slot = item & pix_mask;
                 atomicAdd(&s_acc[wave][0][slot], L.x);  // Scene.cpp:148
                 atomicAdd(&s_acc[wave][1][slot], L.y);
                 atomicAdd(&s_acc[wave][2][slot], L.z);
                 rays += segs;
                 if (kSamples) {
-                    const uint32_t i = x0 + (slot & 7u), j = y0 + (slot >> 3);
-                    size_t k = (size_t)(j * a.width + i) * a.spp_count + (item >> 6);
+                    const uint32_t i = x0 + (slot & (tile_w - 1u)), j = y0 + (slot >> twl);
+                    size_t k = (size_t)(j * a.width + i) * a.spp_count + (item >> pixl);
                     a.sample_rgb[3 * k + 0] = L.x;
                     a.sample_rgb[3 * k + 1] = L.y;
                     a.sample_rgb[3 * k + 2] = L.z;
@@ -1054,7 +1056,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES) trace_kernel(const
     }
 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const uint32_t sx = lane & 7u, sy = lane >> 3;
+    const uint32_t sx = lane & (tile_w - 1u), sy = lane >> twl;
     if (a.accum && sx < tw && sy < th) {
         const uint32_t i = x0 + sx, j = y0 + sy;
         float* out = a.accum + ((size_t)(a.height - 1u - j) * a.width + i) * 3u;  // Scene.cpp:151

@@ -153,6 +153,7 @@ struct TraceArgs {
     uint32_t spp_begin, spp_count;
     uint32_t max_depth;
     uint32_t accumulate;
+    uint32_t tile_w_log2, tile_h_log2;  // pixel tile of one wave: 2x2 .. 8x8
     uint64_t seed;
     float* accum;                 // [height][width][3], row 0 = top
     unsigned long long* rays;     // optional
