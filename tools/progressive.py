@@ -1,0 +1,99 @@
+"""Progressive render of the 4K configuration (Cornell + extra glass / metal, 3840x2160,
+steps of 256 spp): per-step throughput, RMSE against an independent ground truth as a
+function of the accumulated spp, and preview images at a few steps.
+
+    python tools/progressive.py [--steps 64] [--spp-per-step 256] [--width 3840] [--height 2160]
+                                [--out gpurun_out/progressive]
+
+The ground truth is a separate render (other seed, deterministic mode) of the same scene at
+1/4 resolution per axis and 16x the per-pixel samples of the final frame's 4x4 pixel blocks;
+RMSE is taken on the 4x4 box-filtered frame, so it measures the estimator, not the pixel grid.
+One JSON line per step, then a summary line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="cornell_extra")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--spp-per-step", type=int, default=256)
+    ap.add_argument("--gt-spp", type=int, default=65536)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "progressive"))
+    ap.add_argument("--previews", default="1,4,16,64")
+    args = ap.parse_args()
+
+    import torch
+
+    from raytrace_amd import api
+
+    w, h = args.width, args.height
+    assert w % 4 == 0 and h % 4 == 0
+    os.makedirs(args.out, exist_ok=True)
+    ctx = api.Context(0)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev)
+
+    # ground truth at quarter resolution (same camera: the aspect ratio is unchanged)
+    gw, gh = w // 4, h // 4
+    ctx.upload(api.HostScene(args.scene, gw, gh), api.RTX_ACCEL_AUTO)
+    gt = torch.zeros((gh, gw, 3), dtype=torch.float32, device=dev)
+    t0 = time.perf_counter()
+    ctx.render_device(ctx.params(gw, gh, 1 << 24, args.gt_spp, mode=api.RTX_MODE_DETERMINISTIC, seed=4242),
+                      gt.data_ptr(), 0, stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    gt = torch.clamp(gt / args.gt_spp, 0.0, 1.0)  # the 8-bit image clamps too (TonemapFilter.h:8-10)
+    print(json.dumps({"ground_truth": f"{gw}x{gh}, {args.gt_spp} spp, deterministic, seed 4242",
+                      "seconds": time.perf_counter() - t0}), flush=True)
+
+    ctx.upload(api.HostScene(args.scene, w, h), api.RTX_ACCEL_AUTO)
+    step = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+    frame = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+    rays = torch.zeros(1, dtype=torch.int64, device=dev)
+    previews = {int(x) for x in args.previews.split(",") if x}
+    rows = []
+    for k in range(args.steps):
+        rays.zero_()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        ctx.render_device(ctx.params(w, h, k * args.spp_per_step, args.spp_per_step, mode=api.RTX_MODE_FAST, seed=0),
+                          step.data_ptr(), rays.data_ptr(), stream.cuda_stream)
+        b.record(stream)
+        frame.add_(step)
+        spp = (k + 1) * args.spp_per_step
+        # 4x4 box filter of the running mean (= the quarter-resolution pixel integral), clamped
+        # like the ground truth
+        small = (frame / spp).reshape(gh, 4, gw, 4, 3).mean(dim=(1, 3))
+        mean = torch.clamp(small, 0.0, 1.0)
+        rmse = float(torch.sqrt(torch.mean((mean - gt) ** 2)).item())
+        torch.cuda.synchronize(dev)
+        ms = a.elapsed_time(b)
+        r = int(rays.item())
+        row = {"step": k + 1, "spp": spp, "kernel_ms": ms, "grays_per_s": r / ms / 1e6, "rmse": rmse}
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+        if (k + 1) in previews:
+            # quarter-resolution preview through the reference's filter chain (Image.h:30-39)
+            img = api.resolve_host(small.cpu().numpy(), 1)
+            api.write_bmp(os.path.join(args.out, f"preview_{spp:06d}spp.bmp"), img)
+    # RMSE of a Monte Carlo mean falls as spp^-1/2 until the ground truth's own noise floor
+    first, last = rows[0], rows[-1]
+    slope = np.log(last["rmse"] / first["rmse"]) / np.log(last["spp"] / first["spp"]) if len(rows) > 1 else float("nan")
+    print(json.dumps({"summary": True, "scene": args.scene, "width": w, "height": h, "steps": args.steps,
+                      "spp_per_step": args.spp_per_step, "mean_grays_per_s": float(np.mean([r["grays_per_s"] for r in rows])),
+                      "rmse_first": first["rmse"], "rmse_last": last["rmse"], "loglog_slope": float(slope)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
