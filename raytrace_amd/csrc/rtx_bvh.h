@@ -15,7 +15,7 @@
 namespace rtxbvh {
 
 // Maximum tree depth the traversal stack supports (see kBvhStack in rtx_core.h).
-constexpr int kMaxDepth = 30;
+constexpr int kMaxDepth = 22;
 
 // nodes[0] is the root (two-child nodes, see rtxd::BvhNode); `items` are the groups in leaf
 // order.  Returns false (and sets err) if the tree cannot be built within kMaxDepth.

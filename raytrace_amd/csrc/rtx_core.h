@@ -574,7 +574,7 @@ RTX_DEV uint32_t original_prim(const SceneView& sc, uint32_t prim, bool bvh) {
 // Traversal order differs from list order, so ties are resolved explicitly by
 // that rule; everything else (each primitive's own candidate t) does not depend
 // on the order of the scan.
-constexpr int kBvhStack = 32;  // >= rtxbvh::kMaxDepth + 1: one deferred child per level
+constexpr int kBvhStack = 24;  // >= rtxbvh::kMaxDepth + 1: one deferred child per level
 
 RTX_DEV bool tie_wins(uint32_t cand, bool cand_is_rect, uint32_t cur, bool cur_is_rect) {
     if (cand_is_rect && cur_is_rect) return cand > cur;
@@ -582,11 +582,15 @@ RTX_DEV bool tie_wins(uint32_t cand, bool cand_is_rect, uint32_t cur, bool cur_i
     return cand < cur;
 }
 
-// Conservative ray / box test (the builder pads the boxes); returns the entry distance.
-RTX_DEV bool slab(const float lo[3], const float hi[3], V3 o, V3 inv, float t0, float t1, float& t_near) {
-    float tx0 = (lo[0] - o.x) * inv.x, tx1 = (hi[0] - o.x) * inv.x;
-    float ty0 = (lo[1] - o.y) * inv.y, ty1 = (hi[1] - o.y) * inv.y;
-    float tz0 = (lo[2] - o.z) * inv.z, tz1 = (hi[2] - o.z) * inv.z;
+// Conservative ray / box test (the builder pads the boxes by far more than the rounding of
+// these products); returns the entry distance.  noi = -o * inv, so a plane distance is one
+// fma.  inv must be finite (the caller clamps it): with an infinite one, lo * inv + noi is
+// -inf for a negative lo but NaN for a positive hi, and min / max would then keep the -inf
+// and reject a box the parallel ray runs through.
+RTX_DEV bool slab(const float lo[3], const float hi[3], V3 inv, V3 noi, float t0, float t1, float& t_near) {
+    float tx0 = __builtin_fmaf(lo[0], inv.x, noi.x), tx1 = __builtin_fmaf(hi[0], inv.x, noi.x);
+    float ty0 = __builtin_fmaf(lo[1], inv.y, noi.y), ty1 = __builtin_fmaf(hi[1], inv.y, noi.y);
+    float tz0 = __builtin_fmaf(lo[2], inv.z, noi.z), tz1 = __builtin_fmaf(hi[2], inv.z, noi.z);
     float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t0));
     float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), t1));
     t_near = tn;
@@ -611,7 +615,11 @@ RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool w
     float closest = t1;
     uint32_t best = kNone;
     bool best_is_rect = false;
-    const V3 inv = v3(frcp(d.x), frcp(d.y), frcp(d.z));
+    // |1/d| capped: a ray (all but) parallel to a slab is then inside it for every t or for none
+    constexpr float kBig = 1.0e18f;
+    const V3 inv = v3(__builtin_amdgcn_fmed3f(frcp(d.x), -kBig, kBig), __builtin_amdgcn_fmed3f(frcp(d.y), -kBig, kBig),
+                      __builtin_amdgcn_fmed3f(frcp(d.z), -kBig, kBig));
+    const V3 noi = v3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
     constexpr uint32_t kDone = 0xffffffffu;
     uint32_t ref = 0;  // root node
     for (;;) {
@@ -619,8 +627,8 @@ RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool w
         while (ref != kDone && !(ref & kBvhLeaf)) {
             const BvhNode N = sc.bvh[ref];
             float n0, n1;
-            const bool h0 = slab(N.lo0, N.hi0, o, inv, t0, closest, n0);
-            const bool h1 = slab(N.lo1, N.hi1, o, inv, t0, closest, n1);
+            const bool h0 = slab(N.lo0, N.hi0, inv, noi, t0, closest, n0);
+            const bool h1 = slab(N.lo1, N.hi1, inv, noi, t0, closest, n1);
             if (h0 & h1) {
                 const bool first0 = n0 <= n1;
                 if (sp < (uint32_t)kBvhStack) s_stack[sp][tid] = first0 ? N.child1 : N.child0;
