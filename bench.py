@@ -45,16 +45,19 @@ WORKLOADS = {
 }
 
 
-def load_flops_per_ray(scene: str) -> tuple[float, str]:
+def load_flops_per_ray(scene: str, bvh: bool):
     """Algorithmic fp32 operations per ray, counted by the op-counting build of the CPU
-    restatement (tests/golden/flops_per_ray.json, made by tools/count_flops.py)."""
+    restatement (tests/golden/flops_per_ray.json, made by tests/golden/make_golden.py): the
+    reference's O(N) scan for scenes rendered by the scan, the restatement's own hierarchy
+    traversal for scenes rendered through the BVH.  (None, reason) when no count exists."""
     path = os.path.join(ROOT, "tests", "golden", "flops_per_ray.json")
+    key = scene + ":bvh" if bvh else scene
     try:
         with open(path) as f:
             table = json.load(f)
-        return float(table[scene]["flops_per_ray"]), "counted"
+        return float(table[key]["flops_per_ray"]), "counted (BVH traversal of the CPU restatement)" if bvh else "counted"
     except Exception:
-        return 375.0, "hand estimate"
+        return None, f"no count for {key}"
 
 
 def load_hbm_traffic(workload: str, spp: int):
@@ -205,11 +208,7 @@ def main() -> int:
 
     if rank == 0:
         samples = w * h * spp * world * args.steps
-        flops_per_ray, flops_src = load_flops_per_ray(scene_name)
-        if info.accel == api.RTX_ACCEL_BVH:
-            # the counted figure is the reference's O(N) scan; the tree's own traversal is not
-            # op-counted, so no flop rate is claimed for these workloads
-            flops_per_ray, flops_src = None, "not counted for BVH traversal"
+        flops_per_ray, flops_src = load_flops_per_ray(scene_name, info.accel == api.RTX_ACCEL_BVH)
         avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
         rays_per_launch = my_rays / args.steps
         achieved_tflops = None if flops_per_ray is None else flops_per_ray * rays_per_launch / avg_kernel_s / 1e12

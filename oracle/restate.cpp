@@ -22,6 +22,7 @@
  * reference performs counts 1; compares, negation, abs, selects and the integer
  * random stream count 0).
  */
+#include <algorithm>
 #include <atomic>
 #include <cfloat>
 #include <cmath>
@@ -110,6 +111,130 @@ template <class F> Vec<F> rotate(F qx, F qy, F qz, F qw, const Vec<F>& v) {
                   (((tw * qz) + (tz * qw)) - (tx * qy)) + (ty * qx));
 }
 
+// ---------------------------------------------------------------------------
+// optional bounding-volume hierarchy (the reference has none: ShapeList::hit is O(N))
+// ---------------------------------------------------------------------------
+// Only the order in which primitives are visited changes.  Which hit wins does not: a
+// candidate's own t never depends on that order, and among candidates that tie for the
+// minimum the scan of ShapeList.cpp:5-17 keeps the LAST Rect in list order if any Rect ties
+// (Rect.cpp:17 accepts t == t1) and otherwise the FIRST Sphere (Sphere.cpp:15 needs t < t1);
+// world_hit_bvh applies that rule explicitly.  Built by this file alone (median split over
+// item centroids), not by the renderer's builder.
+struct BvhItem {  // a bare primitive, or a run of primitives under one transform chain
+    uint32_t prim_begin, prim_end;
+    double lo[3], hi[3];  // world-space bounds, padded
+};
+struct BvhNodeCpu {
+    float lo[3], hi[3];
+    int left = -1, right = -1;  // children, or
+    int first = 0, count = 0;   // leaf: items [first, first + count)
+};
+struct Bvh {
+    std::vector<BvhItem> items;
+    std::vector<BvhNodeCpu> nodes;
+};
+
+void quat_rotate_d(const double q[4], double v[3]) {  // quat_aos.h:400-412 in double
+    const double tx = q[3] * v[0] + q[1] * v[2] - q[2] * v[1], ty = q[3] * v[1] + q[2] * v[0] - q[0] * v[2];
+    const double tz = q[3] * v[2] + q[0] * v[1] - q[1] * v[0], tw = q[0] * v[0] + q[1] * v[1] + q[2] * v[2];
+    const double r[3] = {tw * q[0] + tx * q[3] - ty * q[2] + tz * q[1], tw * q[1] + ty * q[3] - tz * q[0] + tx * q[2],
+                         tw * q[2] + tz * q[3] - tx * q[1] + ty * q[0]};
+    v[0] = r[0]; v[1] = r[1]; v[2] = r[2];
+}
+
+void prim_local_bounds(const RtxScene& sc, uint32_t p, double lo[3], double hi[3]) {
+    const double a = sc.prim_a[p], b = sc.prim_b[p], c = sc.prim_c[p], d = sc.prim_d[p], e = sc.prim_e[p];
+    switch (sc.prim_kind[p]) {
+        case RTX_PRIM_SPHERE: {
+            const double r = std::fabs(d);
+            lo[0] = a - r; lo[1] = b - r; lo[2] = c - r; hi[0] = a + r; hi[1] = b + r; hi[2] = c + r;
+            break;
+        }
+        case RTX_PRIM_RECT_XY: lo[0] = a; hi[0] = b; lo[1] = c; hi[1] = d; lo[2] = hi[2] = e; break;
+        case RTX_PRIM_RECT_XZ: lo[0] = a; hi[0] = b; lo[2] = c; hi[2] = d; lo[1] = hi[1] = e; break;
+        default: lo[1] = a; hi[1] = b; lo[2] = c; hi[2] = d; lo[0] = hi[0] = e; break;
+    }
+}
+
+int build_node(Bvh& bvh, int begin, int end) {
+    BvhNodeCpu node;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, clo[3] = {1e300, 1e300, 1e300},
+           chi[3] = {-1e300, -1e300, -1e300};
+    for (int k = begin; k < end; ++k)
+        for (int a = 0; a < 3; ++a) {
+            const BvhItem& it = bvh.items[k];
+            lo[a] = std::min(lo[a], it.lo[a]);
+            hi[a] = std::max(hi[a], it.hi[a]);
+            const double c = 0.5 * (it.lo[a] + it.hi[a]);
+            clo[a] = std::min(clo[a], c);
+            chi[a] = std::max(chi[a], c);
+        }
+    for (int a = 0; a < 3; ++a) {  // outward rounding to float
+        node.lo[a] = std::nextafterf((float)lo[a], -INFINITY);
+        node.hi[a] = std::nextafterf((float)hi[a], INFINITY);
+    }
+    const int index = (int)bvh.nodes.size();
+    bvh.nodes.push_back(node);
+    if (end - begin <= 2) {
+        bvh.nodes[index].first = begin;
+        bvh.nodes[index].count = end - begin;
+        return index;
+    }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+        if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+    const int mid = (begin + end) / 2;
+    std::nth_element(bvh.items.begin() + begin, bvh.items.begin() + mid, bvh.items.begin() + end,
+                     [axis](const BvhItem& x, const BvhItem& y) { return x.lo[axis] + x.hi[axis] < y.lo[axis] + y.hi[axis]; });
+    const int l = build_node(bvh, begin, mid);
+    const int r = build_node(bvh, mid, end);
+    bvh.nodes[index].left = l;
+    bvh.nodes[index].right = r;
+    return index;
+}
+
+Bvh build_bvh(const RtxScene& sc) {
+    Bvh bvh;
+    uint32_t p = 0;
+    while (p < sc.n_prims) {
+        const uint32_t chain = sc.prim_chain[p];
+        const uint32_t sb = sc.chain_begin[chain], se = sc.chain_begin[chain + 1];
+        BvhItem it;
+        it.prim_begin = p;
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        do {  // an untransformed primitive is an item of its own, a transformed run stays together
+            double l[3], h[3];
+            prim_local_bounds(sc, p, l, h);
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); }
+            ++p;
+        } while (se > sb && p < sc.n_prims && sc.prim_chain[p] == chain);
+        it.prim_end = p;
+        for (int a = 0; a < 3; ++a) { it.lo[a] = 1e300; it.hi[a] = -1e300; }
+        for (int corner = 0; corner < 8; ++corner) {  // local corners out through the wrappers, innermost first
+            double v[3] = {corner & 1 ? hi[0] : lo[0], corner & 2 ? hi[1] : lo[1], corner & 4 ? hi[2] : lo[2]};
+            for (uint32_t s = se; s > sb; --s) {
+                const uint32_t k = s - 1;
+                if (sc.step_kind[k] == RTX_STEP_TRANSLATE) {
+                    v[0] += sc.step_x[k]; v[1] += sc.step_y[k]; v[2] += sc.step_z[k];
+                } else {
+                    const double q[4] = {sc.step_x[k], sc.step_y[k], sc.step_z[k], sc.step_w[k]};
+                    quat_rotate_d(q, v);
+                }
+            }
+            for (int a = 0; a < 3; ++a) { it.lo[a] = std::min(it.lo[a], v[a]); it.hi[a] = std::max(it.hi[a], v[a]); }
+        }
+        double mag = 0.0;
+        for (int a = 0; a < 3; ++a) mag = std::max(mag, std::max(std::fabs(it.lo[a]), std::fabs(it.hi[a])));
+        for (int a = 0; a < 3; ++a) {  // fp32 slack of the transformed tests
+            it.lo[a] -= 1e-3 * mag + 1e-4;
+            it.hi[a] += 1e-3 * mag + 1e-4;
+        }
+        bvh.items.push_back(it);
+    }
+    if (!bvh.items.empty()) build_node(bvh, 0, (int)bvh.items.size());
+    return bvh;
+}
+
 template <class F>
 struct Hit {  // HitRec.h:3-10
     F t;
@@ -126,7 +251,7 @@ struct Hit {  // HitRec.h:3-10
 template <class F>
 class Tracer {
 public:
-    Tracer(const RtxScene& s, int max_depth) : sc(s), m_max_depth(max_depth) {}
+    Tracer(const RtxScene& s, int max_depth, const Bvh* bvh = nullptr) : sc(s), m_max_depth(max_depth), m_bvh(bvh) {}
     RtxRng rng{0u, 1u};
     unsigned long long segments = 0;
 
@@ -172,6 +297,7 @@ public:
     // inside the run is carried back out once (Rotate.cpp:12-13, Translate.cpp:9).
     bool world_hit(const Vec<F>& o, const Vec<F>& d, F t0, F t1, Hit<F>& rec) {
         ++segments;
+        if (m_bvh) return world_hit_bvh(o, d, t0, t1, rec);
         F closest = t1;
         bool any = false;
         uint32_t p = 0;
@@ -227,6 +353,100 @@ public:
                 }
                 rec = local;
                 any = true;
+            }
+        }
+        return any;
+    }
+
+    // The same nearest hit through the hierarchy.  Slab test per node: 6 subtractions and 6
+    // multiplications (counted), min / max (not counted, like every comparison).
+    bool world_hit_bvh(const Vec<F>& o, const Vec<F>& d, F t0, F t1, Hit<F>& rec) {
+        const Vec<F> inv(F(1.0f) / d.x, F(1.0f) / d.y, F(1.0f) / d.z);
+        F closest = t1;
+        bool any = false, best_is_rect = false;
+        int stack[64], sp = 0;
+        if (m_bvh->nodes.empty()) return false;
+        stack[sp++] = 0;
+        while (sp > 0) {
+            const BvhNodeCpu& N = m_bvh->nodes[stack[--sp]];
+            float tn = raw(t0), tf = raw(closest);
+            bool miss = false;
+            for (int a = 0; a < 3; ++a) {
+                const float ta = raw((F(N.lo[a]) - o.at(a)) * inv.at(a)), tb = raw((F(N.hi[a]) - o.at(a)) * inv.at(a));
+                if (ta != ta || tb != tb) continue;  // 0 * inf: the ray lies in a bounding plane
+                tn = std::max(tn, std::min(ta, tb));
+                tf = std::min(tf, std::max(ta, tb));
+                if (tn > tf) { miss = true; break; }
+            }
+            if (miss) continue;
+            if (N.count == 0) {
+                if (sp + 2 > 64) return any;  // cannot happen: median splits keep the depth at log2(items)
+                stack[sp++] = N.left;
+                stack[sp++] = N.right;
+                continue;
+            }
+            for (int k = N.first; k < N.first + N.count; ++k) {
+                const BvhItem& it = m_bvh->items[k];
+                const uint32_t chain = sc.prim_chain[it.prim_begin];
+                const uint32_t sb = sc.chain_begin[chain], se = sc.chain_begin[chain + 1];
+                Vec<F> ro = o, rd = d;
+                for (uint32_t s = sb; s < se; ++s) {  // Translate.cpp:7, Rotate.cpp:7-9
+                    if (sc.step_kind[s] == RTX_STEP_TRANSLATE) {
+                        ro = ro - Vec<F>(sc.step_x[s], sc.step_y[s], sc.step_z[s]);
+                    } else {
+                        F qx = -sc.step_x[s], qy = -sc.step_y[s], qz = -sc.step_z[s], qw = sc.step_w[s];
+                        ro = rotate(qx, qy, qz, qw, ro);
+                        rd = rotate(qx, qy, qz, qw, rd);
+                    }
+                }
+                for (uint32_t p = it.prim_begin; p < it.prim_end; ++p) {
+                    const uint32_t kind = sc.prim_kind[p];
+                    const bool is_rect = kind != RTX_PRIM_SPHERE;
+                    F t;
+                    bool ok;
+                    // the primitive's own candidate: the upper end of the window is open for a
+                    // sphere and closed for a rect, exactly as when it is the scan's current t1
+                    if (is_rect)
+                        ok = rect_hit(kind, sc.prim_a[p], sc.prim_b[p], sc.prim_c[p], sc.prim_d[p], sc.prim_e[p], ro, rd, t0, closest, t);
+                    else
+                        ok = sphere_hit(Vec<F>(sc.prim_a[p], sc.prim_b[p], sc.prim_c[p]), F(sc.prim_d[p]), ro, rd, t0, t1, t) &&
+                             !(t > closest);
+                    if (!ok) continue;
+                    bool take = !any || t < closest;
+                    if (!take) {  // tie with the current winner
+                        const uint32_t cur = (uint32_t)rec.prim;
+                        if (is_rect && best_is_rect) take = p > cur;
+                        else if (is_rect != best_is_rect) take = is_rect;
+                        else take = p < cur;
+                    }
+                    if (!take) continue;
+                    closest = t;
+                    any = true;
+                    best_is_rect = is_rect;
+                    Hit<F> local;
+                    local.t = t;
+                    local.p = ro + rd * t;
+                    if (!is_rect)
+                        local.n = (local.p - Vec<F>(sc.prim_a[p], sc.prim_b[p], sc.prim_c[p])) / F(sc.prim_d[p]);
+                    else
+                        local.n = Vec<F>(kind == RTX_PRIM_RECT_YZ ? 1.0f : 0.0f, kind == RTX_PRIM_RECT_XZ ? 1.0f : 0.0f,
+                                         kind == RTX_PRIM_RECT_XY ? 1.0f : 0.0f);
+                    fill_uv(p, kind, ro, rd, t, local);
+                    if (sc.prim_flip[p]) local.n = -local.n;
+                    local.prim = (int)p;
+                    local.material = sc.prim_material[p];
+                    for (uint32_t s = se; s > sb; --s) {  // Rotate.cpp:12-13, Translate.cpp:9
+                        const uint32_t q = s - 1;
+                        if (sc.step_kind[q] == RTX_STEP_TRANSLATE) {
+                            local.p = local.p + Vec<F>(sc.step_x[q], sc.step_y[q], sc.step_z[q]);
+                        } else {
+                            F qx = sc.step_x[q], qy = sc.step_y[q], qz = sc.step_z[q], qw = sc.step_w[q];
+                            local.p = rotate(qx, qy, qz, qw, local.p);
+                            local.n = rotate(qx, qy, qz, qw, local.n);
+                        }
+                    }
+                    rec = local;
+                }
             }
         }
         return any;
@@ -464,7 +684,10 @@ public:
 private:
     const RtxScene& sc;
     int m_max_depth;
+    const Bvh* m_bvh;
 };
+
+std::atomic<int> g_use_bvh(0);
 
 template <class F>
 int render_impl(const RtxScene* scene, int nx, int ny, int spp_begin, int spp_count, uint64_t seed, int max_depth,
@@ -473,8 +696,11 @@ int render_impl(const RtxScene* scene, int nx, int ny, int spp_begin, int spp_co
     if (!scene || nx <= 0 || ny <= 0 || spp_count < 0) return -1;
     std::atomic<int> next_row(0);
     std::atomic<unsigned long long> rays(0), flops(0);
+    Bvh bvh;
+    const bool use_bvh = g_use_bvh.load() != 0;
+    if (use_bvh) bvh = build_bvh(*scene);
     auto worker = [&]() {
-        Tracer<F> tr(*scene, max_depth);
+        Tracer<F> tr(*scene, max_depth, use_bvh ? &bvh : nullptr);
         g_flops = 0;
         for (;;) {
             int j = next_row.fetch_add(1);
@@ -537,10 +763,16 @@ int restate_count_flops(const RtxScene* scene, int nx, int ny, int spp_begin, in
                                 total_rays, total_flops);
 }
 
+/* 1: later calls walk this file's own bounding-volume hierarchy instead of scanning the list. */
+void restate_set_bvh(int on) { g_use_bvh.store(on); }
+
 /* Nearest hit of n rays (Shape::hit of the world). */
 int restate_hit(const RtxScene* scene, uint32_t n, const float* org, const float* dir, float t0, float t1, RtxHit* hits) {
     if (!scene) return -1;
-    Tracer<float> tr(*scene, 50);
+    Bvh bvh;
+    const bool use_bvh = g_use_bvh.load() != 0;
+    if (use_bvh) bvh = build_bvh(*scene);
+    Tracer<float> tr(*scene, 50, use_bvh ? &bvh : nullptr);
     for (uint32_t k = 0; k < n; ++k) {
         Hit<float> rec;
         Vec<float> o(org[3 * k], org[3 * k + 1], org[3 * k + 2]), d(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);

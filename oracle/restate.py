@@ -32,6 +32,8 @@ def load() -> C.CDLL:
         lib.restate_hit.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         lib.restate_hit.restype = C.c_int
         lib.restate_image_write.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        lib.restate_set_bvh.argtypes = [C.c_int]
+        lib.restate_set_bvh.restype = None
         _lib = lib
     return _lib
 
@@ -43,7 +45,25 @@ def _scene_ptr(scene):
     return C.cast(C.pointer(scene), C.c_void_p)
 
 
-def render(scene, w, h, spp_begin, spp_count, seed=0, threads=1, per_sample=False, max_depth=50):
+class _accel:
+    """Scope in which the restatement walks its own BVH instead of scanning the list."""
+
+    def __init__(self, bvh):
+        self.bvh = bool(bvh)
+
+    def __enter__(self):
+        load().restate_set_bvh(1 if self.bvh else 0)
+
+    def __exit__(self, *exc):
+        load().restate_set_bvh(0)
+
+
+def render(scene, w, h, spp_begin, spp_count, seed=0, threads=1, per_sample=False, max_depth=50, bvh=False):
+    with _accel(bvh):
+        return _render(scene, w, h, spp_begin, spp_count, seed, threads, per_sample, max_depth)
+
+
+def _render(scene, w, h, spp_begin, spp_count, seed, threads, per_sample, max_depth):
     lib = load()
     n = w * h
     acc = np.zeros((h, w, 3), np.float32)
@@ -60,21 +80,23 @@ def render(scene, w, h, spp_begin, spp_count, seed=0, threads=1, per_sample=Fals
     return out
 
 
-def count_flops(scene, w, h, spp_begin, spp_count, seed=0, threads=1, max_depth=50):
+def count_flops(scene, w, h, spp_begin, spp_count, seed=0, threads=1, max_depth=50, bvh=False):
     lib = load()
     rays, flops = C.c_uint64(0), C.c_uint64(0)
-    rc = lib.restate_count_flops(_scene_ptr(scene), w, h, spp_begin, spp_count, seed, max_depth, threads,
-                                 C.byref(rays), C.byref(flops))
+    with _accel(bvh):
+        rc = lib.restate_count_flops(_scene_ptr(scene), w, h, spp_begin, spp_count, seed, max_depth, threads,
+                                     C.byref(rays), C.byref(flops))
     assert rc == 0
     return {"rays": rays.value, "flops": flops.value}
 
 
-def hit(scene, origins, directions, t0=0.001, t1=3.402823466e+38):
+def hit(scene, origins, directions, t0=0.001, t1=3.402823466e+38, bvh=False):
     lib = load()
     o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
     d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
     hits = np.zeros(o.shape[0], HIT_DTYPE)
-    rc = lib.restate_hit(_scene_ptr(scene), o.shape[0], o.ctypes.data, d.ctypes.data, t0, t1, hits.ctypes.data)
+    with _accel(bvh):
+        rc = lib.restate_hit(_scene_ptr(scene), o.shape[0], o.ctypes.data, d.ctypes.data, t0, t1, hits.ctypes.data)
     assert rc == 0
     return hits
 

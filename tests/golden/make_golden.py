@@ -154,6 +154,14 @@ def flops_per_ray():
         flops[name] = dict(flops_per_ray=c["flops"] / c["rays"], rays=c["rays"], flops=c["flops"], w=w, h=h, spp=spp,
                            note="linear scan, as the reference performs it")
         print("flops/ray", name, flops[name]["flops_per_ray"])
+    # scenes rendered through a hierarchy: the restatement's own traversal is counted (12 per node
+    # visited + the primitive tests it reaches + shading), not the O(N) scan
+    for name, w, h, spp in (("random_field", 240, 135, 2), ("bvh_stress", 240, 135, 1)):
+        hs = api.HostScene(name, w, h)
+        c = restate.count_flops(hs, w, h, 0, spp, seed=0, threads=8, bvh=True)
+        flops[name + ":bvh"] = dict(flops_per_ray=c["flops"] / c["rays"], rays=c["rays"], flops=c["flops"], w=w, h=h, spp=spp,
+                                    note="the restatement's own BVH traversal (median split, leaves of <= 2 items)")
+        print("flops/ray", name + ":bvh", flops[name + ":bvh"]["flops_per_ray"])
     with open(os.path.join(HERE, "flops_per_ray.json"), "w") as f:
         json.dump(flops, f, indent=1, sort_keys=True)
 

@@ -40,6 +40,38 @@ def test_restatement_reproduces_reference_hits(name):
     assert np.array_equal(kinds[got["material"][m]].astype(np.int8), g["mat_kind"][m])
 
 
+@pytest.mark.parametrize("key,meta", [c for c in util.sample_cases()
+                                      if c[1]["scene"] in ("cornell_extra", "random_field", "bvh_stress_500", "textured")])
+def test_restatement_bvh_reproduces_reference_samples(key, meta):
+    """The restatement's own hierarchy (built in oracle/restate.cpp, explicit tie rule) against
+    the reference's O(N) scan: the same paths bit for bit."""
+    g = util.load_golden(key)
+    scene = api.HostScene(meta["scene"], meta["w"], meta["h"])
+    out = restate.render(scene, meta["w"], meta["h"], meta["spp_begin"], meta["spp"], seed=meta["seed"], threads=4,
+                         per_sample=True, bvh=True)
+    util.assert_samples_match(out["samples"], out["segments"], g["samples"], g["segments"], exact=True)
+    assert out["rays"] == meta["rays"]
+
+
+@pytest.mark.parametrize("name", ["cornell", "cornell_extra", "random_field", "bvh_stress_500", "textured"])
+def test_restatement_bvh_reproduces_reference_hits(name):
+    g = util.load_golden("hits_" + name)
+    scene = api.HostScene(name, 32, 32)
+    got = restate.hit(scene, g["origins"], g["directions"], bvh=True)
+    assert np.array_equal(got["hit"], g["hit"].astype(np.int32))
+    m = g["hit"] == 1
+    for field in ("t", "p", "n", "uv"):
+        assert np.array_equal(got[field][m], g[field][m]), field
+
+
+def test_bvh_flop_count_is_far_below_the_scan():
+    scene = api.HostScene("random_field", 48, 27)
+    lin = restate.count_flops(scene, 48, 27, 0, 2, seed=2, threads=4)
+    bvh = restate.count_flops(scene, 48, 27, 0, 2, seed=2, threads=4, bvh=True)
+    assert lin["rays"] == bvh["rays"]
+    assert bvh["flops"] < 0.2 * lin["flops"]
+
+
 def test_restatement_image_write_matches_reference():
     g = util.load_golden("image_write")
     assert np.array_equal(restate.image_write(g["rgb"]), g["rgb8"])
