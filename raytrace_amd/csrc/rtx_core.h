@@ -987,10 +987,11 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES) trace_kernel(const
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t twl = a.tile_w_log2, pixl = a.tile_w_log2 + a.tile_h_log2;  // this wave's pixel tile
     const uint32_t tile_w = 1u << twl, tile_h = 1u << a.tile_h_log2, pix_mask = (1u << pixl) - 1u;
-    const uint32_t tiles_x = (a.width + 2u * tile_w - 1u) / (2u * tile_w);
+    constexpr uint32_t kSide = RTX_BLOCK == 256 ? 2u : 1u;  // waves per block edge
+    const uint32_t tiles_x = (a.width + kSide * tile_w - 1u) / (kSide * tile_w);
     const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
-    const uint32_t x0 = (2u * bx + (wave & 1u)) * tile_w;  // tile origin; rows counted from the bottom
-    const uint32_t y0 = (2u * by + (wave >> 1)) * tile_h;
+    const uint32_t x0 = (kSide * bx + (wave & (kSide - 1u))) * tile_w;  // tile origin; rows counted from the bottom
+    const uint32_t y0 = (kSide * by + (wave >> (kSide - 1u))) * tile_h;
     if (x0 >= a.width || y0 >= a.height) return;  // wave-uniform
     const uint32_t tw = min(tile_w, a.width - x0), th = min(tile_h, a.height - y0);
 
