@@ -74,6 +74,7 @@ struct RtxContext {
     DeviceArray<rtxd::ScanGroup> scan_groups;
     DeviceArray<rtxd::ScanRec> scan_recs;
     DeviceArray<rtxd::ScanHit> scan_info;
+    DeviceArray<rtxd::BvhFastItem> bvh_fast;
     DeviceArray<uint32_t> scan_orig;
     DeviceArray<rtxd::BvhNode> bvh;
     DeviceArray<rtxd::Group> bvh_items;
@@ -298,6 +299,59 @@ void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rt
     sr.push_back(sr.back());  // readable pad record
 }
 
+// Fast-mode leaf records of the BVH items (groups in leaf order) and the hit-completion table
+// in their slot order.
+void build_bvh_fast_items(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::PrimInfo>& info,
+                          const std::vector<rtxd::Group>& items, const std::vector<rtxd::Step>& steps,
+                          std::vector<rtxd::BvhFastItem>& out, std::vector<rtxd::ScanHit>& si, std::vector<uint32_t>& so) {
+    std::vector<char> used(prims.size(), 0);
+    for (uint32_t g = 0; g < items.size(); ++g) {
+        const rtxd::Group& G = items[g];
+        rtxd::ScanGroup S{};
+        compose_chain(steps, G.step_begin, G.step_end, S.m);
+        S.identity = G.step_end == G.step_begin ? 1u : 0u;
+        rtxd::BvhFastItem I{};
+        I.slot = (uint32_t)si.size();
+        const uint32_t n = G.prim_end - G.prim_begin;
+        const uint32_t group_of_prims = prims[G.prim_begin].group;
+        auto push = [&](uint32_t p) {
+            si.push_back(make_scan_hit(prims[p], info[p], S, group_of_prims));
+            so.push_back(p);
+        };
+        std::vector<std::array<uint32_t, 6>> boxes;
+        if (n == 6) boxes = find_boxes(prims, G.prim_begin, G.prim_end, used);
+        if (n == 1 && S.identity) {
+            const rtxd::Prim& P = prims[G.prim_begin];
+            I.type = P.kind_flip & 3u;  // kBvhItemRect* / kBvhItemSphere = RTX_PRIM_*
+            I.f[0] = P.a; I.f[1] = P.b; I.f[2] = P.c;
+            I.f[3] = I.type == rtxd::kBvhItemSphere ? P.d * P.d : P.d;
+            I.f[4] = P.e;
+            I.count = 1;
+            push(G.prim_begin);
+        } else if (boxes.size() == 1) {
+            const auto& box = boxes[0];
+            const rtxd::Prim &ZH = prims[box[0]], &ZL = prims[box[1]];
+            const double lo[3] = {ZH.a, ZH.c, ZL.e}, hi[3] = {ZH.b, ZH.d, ZH.e};
+            for (int i = 0; i < 3; ++i) {
+                const double inv = 1.0 / (hi[i] - lo[i]);
+                for (int j = 0; j < 3; ++j) I.f[3 * i + j] = (float)(S.m[3 * i + j] * inv);
+                I.f[9 + i] = (float)((S.m[9 + i] - lo[i]) * inv);
+            }
+            I.type = rtxd::kBvhItemBox;
+            I.count = 6;
+            for (uint32_t f = 0; f < 6; ++f) push(box[f]);
+        } else {
+            for (uint32_t p = G.prim_begin; p < G.prim_end; ++p) used[p] = 0;  // a partial box match
+            std::memcpy(I.f, S.m, sizeof I.f);
+            I.type = rtxd::kBvhItemGroup;
+            I.aux = G.prim_begin;
+            I.count = n;
+            for (uint32_t p = G.prim_begin; p < G.prim_end; ++p) push(p);
+        }
+        out.push_back(I);
+    }
+}
+
 int check_params(const RtxContext* ctx, const RtxParams* p) {
     if (!ctx) return fail(RTX_ERR_INVALID_ARGUMENT, "context is null");
     if (!p) return fail(RTX_ERR_INVALID_ARGUMENT, "params is null");
@@ -459,9 +513,11 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     if (!use_bvh) build_scan_table(prims, info, groups, steps, scan_groups, scan_recs, scan_info, scan_orig);
     std::vector<rtxd::BvhNode> nodes;
     std::vector<rtxd::Group> items;
+    std::vector<rtxd::BvhFastItem> fast_items;
     if (use_bvh) {
         std::string err;
         if (!rtxbvh::build(prims, groups, steps, nodes, items, err)) return fail(RTX_ERR_TOO_LARGE, err);
+        build_bvh_fast_items(prims, info, items, steps, fast_items, scan_info, scan_orig);
     }
 
     RTX_HIP(ctx->prims.upload(prims_padded));
@@ -478,6 +534,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     RTX_HIP(ctx->scan_orig.upload(scan_orig));
     RTX_HIP(ctx->bvh.upload(nodes));
     RTX_HIP(ctx->bvh_items.upload(items));
+    RTX_HIP(ctx->bvh_fast.upload(fast_items));
 
     rtxd::SceneView& v = ctx->view;
     v.prims = ctx->prims.ptr;
@@ -490,12 +547,13 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     v.lights = ctx->lights.ptr;
     v.scan_groups = use_bvh ? nullptr : ctx->scan_groups.ptr;
     v.scan_recs = use_bvh ? nullptr : ctx->scan_recs.ptr;
-    v.scan_info = use_bvh ? nullptr : ctx->scan_info.ptr;
-    v.scan_orig = use_bvh ? nullptr : ctx->scan_orig.ptr;
+    v.scan_info = ctx->scan_info.ptr;
+    v.scan_orig = ctx->scan_orig.ptr;
     v.n_scan_groups = (uint32_t)scan_groups.size();
     v.scan_pad_ = 0;
     v.bvh = use_bvh ? ctx->bvh.ptr : nullptr;
     v.bvh_items = use_bvh ? ctx->bvh_items.ptr : nullptr;
+    v.bvh_fast = use_bvh ? ctx->bvh_fast.ptr : nullptr;
     v.n_prims = s->n_prims;
     v.n_groups = (uint32_t)groups.size();
     v.n_steps = s->n_steps;

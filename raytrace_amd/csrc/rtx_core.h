@@ -405,6 +405,39 @@ RTX_DEV uint32_t original_prim(const SceneView&, uint32_t prim, bool) { return p
 #else
 // Fast mode: the bucketed table (ScanGroup / ScanRec): per group one composed affine map and
 // four homogeneous loops (XY, XZ, YZ rects, spheres) whose bodies are branch-free.
+// Complete the record of the winner of a fast-mode query (per lane): one 64-byte record in
+// world space, no transform.  `slot` is a position of scan_info / scan_orig.
+RTX_DEV void finish_scan_hit(const SceneView& sc, uint32_t slot, float t, V3 o, V3 d, bool want_uv, HitRec& rec) {
+    const ScanHit I = sc.scan_info[slot];
+    const V3 p = o + d * t;
+    const V3 pc = p - v3(I.c);
+    rec.t = t;
+    rec.p = p;
+    rec.n = v3(__builtin_fmaf(pc.x, I.inv_r, I.n0[0]), __builtin_fmaf(pc.y, I.inv_r, I.n0[1]),
+               __builtin_fmaf(pc.z, I.inv_r, I.n0[2]));
+    rec.prim = slot;
+    rec.bits = I.bits;
+    rec.texture = I.texture;
+    rec.param = I.param;
+    rec.color = v3(I.r, I.g, I.b);
+    rec.u = rec.v = 0.0f;
+    if (want_uv || (I.bits & kInfoNeedsUV)) {  // texture coordinates live in the primitive's frame
+        const Prim W = sc.prims[sc.scan_orig[slot]];
+        const uint32_t kind = I.bits & kInfoKindMask;
+        V3 pl = p, unused = d;
+        if (I.chained) {
+            const Group G = sc.groups[I.group];
+            enter_group<false>(sc, G.step_begin, G.step_end, pl, unused);
+        }
+        if (kind == RTX_PRIM_SPHERE) {
+            V3 nl = (pl - v3(W.a, W.b, W.c)) * frcp(W.d);  // before FlipNormals (Sphere.cpp:19-21)
+            sphere_uv(nl, rec.u, rec.v);
+        } else {
+            rect_uv(kind, W.a, W.b, W.c, W.d, pl, v3(0.0f, 0.0f, 0.0f), 0.0f, rec.u, rec.v);
+        }
+    }
+}
+
 // One rect of the bucketed table against every lane's ray.  The six interval tests are
 // v_cmpx instructions: each one clears the lanes that fail from EXEC, so no mask has to be
 // combined on the scalar unit and the two updates are plain moves under the surviving lanes.
@@ -526,42 +559,11 @@ RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, boo
     }
     if (best == kNone) return false;
 
-    // complete the record of the winner (per lane): one 64-byte record, no transform
-    const ScanHit I = sc.scan_info[best];
-    const V3 p = o + d * closest;
-    const V3 pc = p - v3(I.c);
-    rec.t = closest;
-    rec.p = p;
-    rec.n = v3(__builtin_fmaf(pc.x, I.inv_r, I.n0[0]), __builtin_fmaf(pc.y, I.inv_r, I.n0[1]),
-               __builtin_fmaf(pc.z, I.inv_r, I.n0[2]));
-    rec.prim = best;
-    rec.bits = I.bits;
-    rec.texture = I.texture;
-    rec.param = I.param;
-    rec.color = v3(I.r, I.g, I.b);
-    rec.u = rec.v = 0.0f;
-    if (want_uv || (I.bits & kInfoNeedsUV)) {  // texture coordinates live in the primitive's frame
-        const Prim W = sc.prims[sc.scan_orig[best]];  // the table position of a box face holds no rect
-        const uint32_t kind = I.bits & kInfoKindMask;
-        V3 pl = p;
-        if (I.chained) {
-            const float* m = sc.scan_groups[I.group].m;
-            pl = v3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[9], m[3] * p.x + m[4] * p.y + m[5] * p.z + m[10],
-                    m[6] * p.x + m[7] * p.y + m[8] * p.z + m[11]);
-        }
-        if (kind == RTX_PRIM_SPHERE) {
-            V3 nl = (pl - v3(W.a, W.b, W.c)) * frcp(W.d);  // before FlipNormals (Sphere.cpp:19-21)
-            sphere_uv(nl, rec.u, rec.v);
-        } else {
-            rect_uv(kind, W.a, W.b, W.c, W.d, pl, v3(0.0f, 0.0f, 0.0f), 0.0f, rec.u, rec.v);
-        }
-    }
+    finish_scan_hit(sc, best, closest, o, d, want_uv, rec);
     return true;
 }
 // The fast linear scan reports positions of the bucketed table.
-RTX_DEV uint32_t original_prim(const SceneView& sc, uint32_t prim, bool bvh) {
-    return bvh ? prim : sc.scan_orig[prim];
-}
+RTX_DEV uint32_t original_prim(const SceneView& sc, uint32_t prim, bool) { return sc.scan_orig[prim]; }
 #endif
 
 // ---------------------------------------------------------------------------
@@ -605,6 +607,82 @@ RTX_DEV uint32_t pop_ref(uint32_t (*stack)[256], uint32_t& sp, uint32_t tid) {
     return sp < (uint32_t)kBvhStack ? stack[sp][tid] : kBvhLeaf;
 }
 
+#if !RTX_DET
+// One fast-mode leaf record against this lane's ray (inv / noi: the capped reciprocal
+// direction and -o * inv of the traversal).  Ties between equal distances are not ordered:
+// fast mode only has to be statistically equal.
+RTX_DEV void fast_leaf_item(const SceneView& sc, const BvhFastItem& I, V3 o, V3 d, V3 inv, V3 noi, float t0,
+                            float& closest, uint32_t& best) {
+    if (I.type == kBvhItemSphere) {
+        // roots of a t^2 + 2 h t + c = 0 with h = oc.d (Sphere.cpp:9-15 with b = 2h)
+        const float a = dot(d, d), inv_a = frcp(a);
+        const V3 oc = o - v3(I.f[0], I.f[1], I.f[2]);
+        const float h = dot(oc, d), c = dot(oc, oc) - I.f[3];
+        const float D = h * h - a * c;
+        const float root = fsqrt(D);
+        const float ta = (-h - root) * inv_a, tb = (-h + root) * inv_a;
+        const float t = ta > t0 ? ta : tb;
+        const bool ok = (D > 0.0f) & (t > t0) & (t < closest);
+        closest = ok ? t : closest;
+        best = ok ? I.slot : best;
+    } else if (I.type <= kBvhItemRectYZ) {
+        const bool xy = I.type == kBvhItemRectXY, yz = I.type == kBvhItemRectYZ;
+        // plane coordinate zi, in-plane xi / yi: XY (0,1,2), XZ (0,2,1), YZ (1,2,0)
+        const float iz = xy ? inv.z : (yz ? inv.x : inv.y), nz = xy ? noi.z : (yz ? noi.x : noi.y);
+        const float ox = yz ? o.y : o.x, dx = yz ? d.y : d.x;
+        const float oy = xy ? o.y : o.z, dy = xy ? d.y : d.z;
+        const float t = __builtin_fmaf(I.f[4], iz, nz);
+        const float x = __builtin_fmaf(t, dx, ox), y = __builtin_fmaf(t, dy, oy);
+        const bool ok = (t >= t0) & (t <= closest) & (x >= I.f[0]) & (x <= I.f[1]) & (y >= I.f[2]) & (y <= I.f[3]);
+        closest = ok ? t : closest;
+        best = ok ? I.slot : best;
+    } else if (I.type == kBvhItemBox) {
+        // the box is [0,1]^3 in the record's frame: plane distances are noi and inv + noi
+        const float* m = I.f;
+        const V3 ro = v3(m[0] * o.x + m[1] * o.y + m[2] * o.z + m[9], m[3] * o.x + m[4] * o.y + m[5] * o.z + m[10],
+                         m[6] * o.x + m[7] * o.y + m[8] * o.z + m[11]);
+        const V3 rd = v3(m[0] * d.x + m[1] * d.y + m[2] * d.z, m[3] * d.x + m[4] * d.y + m[5] * d.z,
+                         m[6] * d.x + m[7] * d.y + m[8] * d.z);
+        constexpr float kBig = 1.0e18f;
+        const V3 li = v3(__builtin_amdgcn_fmed3f(frcp(rd.x), -kBig, kBig), __builtin_amdgcn_fmed3f(frcp(rd.y), -kBig, kBig),
+                         __builtin_amdgcn_fmed3f(frcp(rd.z), -kBig, kBig));
+        const float lx = -ro.x * li.x, ly = -ro.y * li.y, lz = -ro.z * li.z;
+        const float hx = lx + li.x, hy = ly + li.y, hz = lz + li.z;
+        const bool px = lx < hx, py = ly < hy, pz = lz < hz;  // travelling towards + along the axis
+        const float nx = px ? lx : hx, fx = px ? hx : lx;
+        const float ny = py ? ly : hy, fy = py ? hy : ly;
+        const float nz = pz ? lz : hz, fz = pz ? hz : lz;
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+        const float tf = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+        const bool enter = tn >= t0;
+        const float t = enter ? tn : tf;
+        const bool ok = (tn <= tf) & (t >= t0) & (t <= closest);
+        const float cx = enter ? nx : fx, cy = enter ? ny : fy;
+        const bool ax = cx == t, ay = cy == t;
+        uint32_t face = ax ? 4u : (ay ? 2u : 0u);
+        const bool towards_plus = ax ? px : (ay ? py : pz);
+        face += (enter == towards_plus) ? 1u : 0u;
+        closest = ok ? t : closest;
+        best = ok ? I.slot + face : best;
+    } else {  // any other transformed group: its primitives one by one in the group's frame
+        const float* m = I.f;
+        const V3 ro = v3(m[0] * o.x + m[1] * o.y + m[2] * o.z + m[9], m[3] * o.x + m[4] * o.y + m[5] * o.z + m[10],
+                         m[6] * o.x + m[7] * o.y + m[8] * o.z + m[11]);
+        const V3 rd = v3(m[0] * d.x + m[1] * d.y + m[2] * d.z, m[3] * d.x + m[4] * d.y + m[5] * d.z,
+                         m[6] * d.x + m[7] * d.y + m[8] * d.z);
+        const RayAux aux = make_aux(ro, rd);
+        for (uint32_t k = 0; k < I.count; ++k) {
+            const Prim P = sc.prims[I.aux + k];
+            float t;
+            if (prim_test(P, ro, rd, aux, t0, closest, t)) {
+                closest = t;
+                best = I.slot + k;
+            }
+        }
+    }
+}
+#endif
+
 // Traversal: each lane descends until it holds a leaf (nearer child first, the other one
 // deferred on its stack), then the lanes of the wave test their leaves together.  The stack
 // lives in LDS, one column per thread (entry e of thread t at [e][t]: conflict-free).
@@ -643,6 +721,7 @@ RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool w
         if (ref == kDone) break;
         // leaf: items [first, first+count)
         const uint32_t first = ref & kBvhLeafFirst, count = (ref >> kBvhLeafCountShift) & 15u;
+#if RTX_DET
         for (uint32_t k = 0; k < count; ++k) {
             const Group G = sc.bvh_items[first + k];
             V3 ro = o, rd = d;
@@ -665,14 +744,21 @@ RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool w
                 }
             }
         }
+#else
+        for (uint32_t k = 0; k < count; ++k) fast_leaf_item(sc, sc.bvh_fast[first + k], o, d, inv, noi, t0, closest, best);
+#endif
         ref = pop_ref(s_stack, sp, tid);
     }
     if (best == kNone) return false;
+#if RTX_DET
     finish_hit(sc, best, closest, o, d, want_uv, rec);
+#else
+    (void)best_is_rect;
+    finish_scan_hit(sc, best, closest, o, d, want_uv, rec);
+#endif
     return true;
 }
 
-// want_uv: fill the texture coordinates even when the hit's texture does not read them.
 template <bool kBvh>
 RTX_DEV bool scene_hit(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec& rec, bool want_uv = false) {
     if (kBvh) return hit_bvh(sc, o, d, t0, t1, want_uv, rec);

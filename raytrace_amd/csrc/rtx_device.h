@@ -122,7 +122,25 @@ constexpr uint32_t kBvhLeaf = 0x80000000u;
 constexpr uint32_t kBvhLeafFirst = 0x07ffffffu;
 constexpr uint32_t kBvhLeafCountShift = 27u;
 
-// A BVH item: one group (a bare primitive is a group of one with an empty chain).
+// Fast-mode leaf record, one per BVH item in leaf order, so that a leaf costs one 64-byte
+// fetch instead of the chain item -> steps -> primitive:
+//   kBvhItemSphere  f = centre xyz, r*r                       (untransformed sphere)
+//   kBvhItemRect*   f = x0 x1 y0 y1 k                         (untransformed rect of that axis)
+//   kBvhItemBox     f = world -> unit-cube affine map (rows of the 3x3, then the offset): a
+//                   complete box under any Translate / Rotate chain; the scaling of the map
+//                   keeps the ray parameter t, so the slab test is against [0,1]^3
+//   kBvhItemGroup   f = world -> group affine map; primitives [aux, aux + count) of `prims`
+// `slot` is the item's first position in scan_info / scan_orig (box: + face, group: + index).
+struct alignas(64) BvhFastItem {
+    float f[12];
+    uint32_t slot;
+    uint32_t aux;
+    uint32_t type;
+    uint32_t count;
+};
+constexpr uint32_t kBvhItemRectXY = 0u, kBvhItemRectXZ = 1u, kBvhItemRectYZ = 2u;  // = RTX_PRIM_*
+constexpr uint32_t kBvhItemSphere = 3u, kBvhItemBox = 4u, kBvhItemGroup = 5u;
+
 struct SceneView {
     const Prim* prims;      // n_prims + 1 records (one readable pad record at the end)
     const PrimInfo* info;   // n_prims records
@@ -132,15 +150,16 @@ struct SceneView {
     const Texture* textures;
     const uint8_t* texels;  // 8-bit RGB image data of all image textures
     const Light* lights;
-    // bucketed copy for the fast-mode linear scan (null when a BVH is used)
+    // bucketed copy for the fast-mode linear scan (scan_groups / scan_recs null when a BVH is used)
     const ScanGroup* scan_groups;
     const ScanRec* scan_recs;      // one per scan position + 1 readable pad record
-    const ScanHit* scan_info;      // in scan order
+    const ScanHit* scan_info;      // in scan order (BVH: in leaf-record slot order)
     const uint32_t* scan_orig;     // scan position -> original primitive index
     uint32_t n_scan_groups;
     uint32_t scan_pad_;
     const BvhNode* bvh;        // null: linear scan over groups
     const Group* bvh_items;    // the groups in leaf order (one load from leaf to primitive range)
+    const BvhFastItem* bvh_fast;  // the same items as fast-mode leaf records
     uint32_t n_prims, n_groups, n_steps, n_materials, n_textures, n_lights, n_bvh_nodes;
     uint32_t light_is_list;
     float cam_origin[3], cam_ll[3], cam_u[3], cam_v[3];

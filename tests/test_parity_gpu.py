@@ -256,8 +256,11 @@ def test_fast_mode_hits_agree_with_golden_up_to_rounding(gpu_ctx, name, accel):
     assert (np.abs(fast["p"][m] - det["p"][m]) / scale).max() < 2e-4
     dlen = np.linalg.norm(g["directions"][m], axis=1)
     assert (np.abs(fast["t"][m] - det["t"][m]) * dlen / scale[:, 0]).max() < 2e-4
-    # a sphere normal is (p - c) / r: the hit point's rounding error divided by a radius of 0.05-0.2
-    assert np.abs(fast["n"][m] - det["n"][m]).max() < 5e-3
+    # a sphere normal is (p - c) / r: the hit point's rounding error (both modes carry one of
+    # |o - c| * 2^-23 * a few) divided by the radius, which is as small as 0.05 in the stress scene
+    radii = a["prim_d"][a["prim_kind"] == 3]
+    n_tol = 5e-3 * max(1.0, 0.2 / float(radii.min())) if radii.size else 5e-3
+    assert np.abs(fast["n"][m] - det["n"][m]).max() < n_tol
     assert np.array_equal(fast["material"][m], det["material"][m])
     # texture coordinates: the sphere's wrap at phi = +-pi maps u = 0 onto u = 1
     du = np.abs(fast["uv"][m] - det["uv"][m])
