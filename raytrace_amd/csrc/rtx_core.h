@@ -407,6 +407,7 @@ RTX_DEV uint32_t original_prim(const SceneView&, uint32_t prim, bool) { return p
 // four homogeneous loops (XY, XZ, YZ rects, spheres) whose bodies are branch-free.
 // Complete the record of the winner of a fast-mode query (per lane): one 64-byte record in
 // world space, no transform.  `slot` is a position of scan_info / scan_orig.
+template <bool kBvh>
 RTX_DEV void finish_scan_hit(const SceneView& sc, uint32_t slot, float t, V3 o, V3 d, bool want_uv, HitRec& rec) {
     const ScanHit I = sc.scan_info[slot];
     const V3 p = o + d * t;
@@ -424,10 +425,17 @@ RTX_DEV void finish_scan_hit(const SceneView& sc, uint32_t slot, float t, V3 o, 
     if (want_uv || (I.bits & kInfoNeedsUV)) {  // texture coordinates live in the primitive's frame
         const Prim W = sc.prims[sc.scan_orig[slot]];
         const uint32_t kind = I.bits & kInfoKindMask;
-        V3 pl = p, unused = d;
+        V3 pl = p;
         if (I.chained) {
-            const Group G = sc.groups[I.group];
-            enter_group<false>(sc, G.step_begin, G.step_end, pl, unused);
+            if (kBvh) {  // no composed map per group there: walk the step chain
+                V3 unused = d;
+                const Group G = sc.groups[I.group];
+                enter_group<false>(sc, G.step_begin, G.step_end, pl, unused);
+            } else {
+                const float* m = sc.scan_groups[I.group].m;
+                pl = v3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[9], m[3] * p.x + m[4] * p.y + m[5] * p.z + m[10],
+                        m[6] * p.x + m[7] * p.y + m[8] * p.z + m[11]);
+            }
         }
         if (kind == RTX_PRIM_SPHERE) {
             V3 nl = (pl - v3(W.a, W.b, W.c)) * frcp(W.d);  // before FlipNormals (Sphere.cpp:19-21)
@@ -559,7 +567,7 @@ RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, boo
     }
     if (best == kNone) return false;
 
-    finish_scan_hit(sc, best, closest, o, d, want_uv, rec);
+    finish_scan_hit<false>(sc, best, closest, o, d, want_uv, rec);
     return true;
 }
 // The fast linear scan reports positions of the bucketed table.
@@ -576,6 +584,9 @@ RTX_DEV uint32_t original_prim(const SceneView& sc, uint32_t prim, bool) { retur
 // Traversal order differs from list order, so ties are resolved explicitly by
 // that rule; everything else (each primitive's own candidate t) does not depend
 // on the order of the scan.
+#ifndef RTX_TRACE_WAVES_BVH
+#define RTX_TRACE_WAVES_BVH 4
+#endif
 constexpr int kBvhStack = 24;  // >= rtxbvh::kMaxDepth + 1: one deferred child per level
 
 RTX_DEV bool tie_wins(uint32_t cand, bool cand_is_rect, uint32_t cur, bool cur_is_rect) {
@@ -754,7 +765,7 @@ RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool w
     finish_hit(sc, best, closest, o, d, want_uv, rec);
 #else
     (void)best_is_rect;
-    finish_scan_hit(sc, best, closest, o, d, want_uv, rec);
+    finish_scan_hit<true>(sc, best, closest, o, d, want_uv, rec);
 #endif
     return true;
 }
@@ -1062,7 +1073,7 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
 // executes in lockstep, so the order of the adds - and with it every bit of the result -
 // is reproducible from run to run.
 template <bool kBvh, bool kSamples>
-__global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES) trace_kernel(const TraceArgs a) {
+__global__ void __launch_bounds__(RTX_BLOCK, kBvh ? RTX_TRACE_WAVES_BVH : RTX_TRACE_WAVES) trace_kernel(const TraceArgs a) {
     __shared__ float s_acc[RTX_BLOCK / 64][3][64];
 #ifdef RTX_PROBE_LDS_BYTES  // occupancy experiments: LDS ballast that caps the resident blocks per CU
     __shared__ float s_ballast[RTX_PROBE_LDS_BYTES / 4];
