@@ -18,6 +18,9 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 RTX_ABI_VERSION = 2
 RTX_ACCEL_AUTO, RTX_ACCEL_LINEAR, RTX_ACCEL_BVH = 0, 1, 2
 RTX_MODE_FAST, RTX_MODE_DETERMINISTIC = 0, 1
+RTX_PRIM_RECT_XY, RTX_PRIM_RECT_XZ, RTX_PRIM_RECT_YZ, RTX_PRIM_SPHERE = 0, 1, 2, 3
+RTX_MAT_LAMBERTIAN, RTX_MAT_METAL, RTX_MAT_DIELECTRIC, RTX_MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
+RTX_TEX_COLOR, RTX_TEX_CHECKER, RTX_TEX_IMAGE = 0, 1, 2
 RTX_OK = 0
 RTX_ERR_INVALID_ARGUMENT, RTX_ERR_NO_DEVICE, RTX_ERR_HIP = -1, -2, -3
 RTX_ERR_NO_SCENE, RTX_ERR_UNSUPPORTED, RTX_ERR_TOO_LARGE = -4, -5, -6

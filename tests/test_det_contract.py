@@ -17,6 +17,11 @@ void det_draws(unsigned pixel, unsigned sample, unsigned long long seed, int n, 
 }
 void det_sincos(int n, const float* x, float* s, float* c) { for (int i = 0; i < n; ++i) rtx_sincosf(x[i], &s[i], &c[i]); }
 float det_tan(float x) { return rtx_tanf(x); }
+#include <math.h>
+void det_atan2(int n, const float* y, const float* x, float* out) { for (int i = 0; i < n; ++i) out[i] = rtx_atan2f(y[i], x[i]); }
+void det_asin(int n, const float* x, float* out) {
+    for (int i = 0; i < n; ++i) out[i] = rtx_asinf_with_root(x[i], sqrtf((1.0f - x[i]) * (1.0f + x[i])));
+}
 """
 
 
@@ -26,7 +31,7 @@ def det(tmp_path_factory):
     (d / "det.c").write_text(SRC)
     so = d / "libdet.so"
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
-                    str(d / "det.c"), "-o", str(so)], check=True)
+                    str(d / "det.c"), "-o", str(so), "-lm"], check=True)
     lib = ctypes.CDLL(str(so))
     lib.det_tan.restype = ctypes.c_float
     lib.det_tan.argtypes = [ctypes.c_float]
@@ -73,3 +78,23 @@ def test_sincos_accuracy(det):
     assert np.abs(s - np.sin(x.astype(np.float64))).max() < 3e-7
     assert np.abs(c - np.cos(x.astype(np.float64))).max() < 3e-7
     assert abs(det.det_tan(0.3490658) - np.tan(0.3490658)) < 1e-6
+
+
+def test_atan2_asin_accuracy(det):
+    """The sphere texture coordinates' atan2 / asin (Util.h:79-80): a few ulp of the libm values
+    over the whole domain, exact at the axes."""
+    rng = np.random.default_rng(1)
+    y = rng.normal(size=200000).astype(np.float32)
+    x = rng.normal(size=200000).astype(np.float32)
+    y[:8] = [0, 0, 1, -1, 1, -1, 0.0, 1e-30]
+    x[:8] = [1, -1, 0, 0, 1, 1, 0.0, -1]
+    out = np.zeros_like(x)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    det.det_atan2(x.size, p(y), p(x), p(out))
+    want = np.arctan2(y.astype(np.float64), x.astype(np.float64))
+    assert np.abs(out - want).max() < 6e-7
+    assert out[0] == 0.0 and out[6] == 0.0 and abs(out[2] - np.pi / 2) < 2e-7
+    s = rng.uniform(-1, 1, 200000).astype(np.float32)
+    s[:3] = [-1, 0, 1]
+    det.det_asin(s.size, p(s), p(out))
+    assert np.abs(out - np.arcsin(s.astype(np.float64))).max() < 6e-7

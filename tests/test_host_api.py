@@ -112,3 +112,48 @@ def test_bmp_writer_matches_reference_bytes(tmp_path):
     path = str(tmp_path / "x.bmp")
     api.write_bmp(path, g["rgb8"])
     assert np.array_equal(np.frombuffer(open(path, "rb").read(), np.uint8), g["bmp_bytes"])
+
+
+# ---------------------------------------------------------------------------
+# ImageTexture (ImageTexture.h:7-29): the host decoders against Pillow
+# ---------------------------------------------------------------------------
+def _textured_texels(path, monkeypatch):
+    monkeypatch.setenv("RTX_TEXTURE", str(path))
+    scene = api.HostScene("textured", 16, 9)
+    a = scene.arrays()
+    images = np.flatnonzero(a["tex_kind"] == api.RTX_TEX_IMAGE)
+    assert images.size >= 1
+    t = int(images[0])
+    w, h, off = int(a["tex_odd"][t]), int(a["tex_even"][t]), int(a["tex_offset"][t])
+    return a["texels"][off:off + w * h * 3].reshape(h, w, 3)
+
+
+def test_image_texture_bmp_loader_matches_pillow(monkeypatch):
+    from PIL import Image
+
+    path = os.path.join(ROOT, "tests", "golden", "texture_64x32.bmp")
+    want = np.asarray(Image.open(path).convert("RGB"))
+    got = _textured_texels(path, monkeypatch)
+    assert got.shape == want.shape == (32, 64, 3)
+    assert np.array_equal(got, want)  # rows top-down, RGB: what stbi_load returns (ImageTexture.h:9)
+
+
+def test_image_texture_ppm_and_padded_bmp(tmp_path, monkeypatch):
+    from PIL import Image
+
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)  # 7 * 3 = 21 bytes per row: BMP pads to 24
+    for name in ("t.ppm", "t.bmp"):
+        Image.fromarray(img).save(tmp_path / name)
+        assert np.array_equal(_textured_texels(tmp_path / name, monkeypatch), img), name
+
+
+def test_missing_texture_file_is_an_error(tmp_path, monkeypatch):
+    monkeypatch.setenv("RTX_TEXTURE", str(tmp_path / "nope.bmp"))
+    with pytest.raises(ValueError):
+        api.HostScene("textured", 16, 9)
+    # an unsupported format is reported by the flattener, not dereferenced
+    (tmp_path / "junk.bmp").write_bytes(b"not an image at all")
+    monkeypatch.setenv("RTX_TEXTURE", str(tmp_path / "junk.bmp"))
+    with pytest.raises(ValueError):
+        api.HostScene("textured", 16, 9)
