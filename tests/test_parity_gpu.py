@@ -256,10 +256,12 @@ def test_fast_mode_hits_agree_with_golden_up_to_rounding(gpu_ctx, name, accel):
     assert (np.abs(fast["p"][m] - det["p"][m]) / scale).max() < 2e-4
     dlen = np.linalg.norm(g["directions"][m], axis=1)
     assert (np.abs(fast["t"][m] - det["t"][m]) * dlen / scale[:, 0]).max() < 2e-4
-    # a sphere normal is (p - c) / r: the hit point's rounding error (both modes carry one of
-    # |o - c| * 2^-23 * a few) divided by the radius, which is as small as 0.05 in the stress scene
+    # a sphere normal is (p - c) / r, and the quadratic of Sphere.cpp:9-12 forms |o - c|^2 - r^2
+    # in fp32: for the stress scene's r = 0.05 spheres seen from 100 units away r^2 is below
+    # one ulp of |o - c|^2, so both modes (and the reference) carry an error in the hit point
+    # that grows with 1 / r, and its effect on the normal with 1 / r^2
     radii = a["prim_d"][a["prim_kind"] == 3]
-    n_tol = 5e-3 * max(1.0, 0.2 / float(radii.min())) if radii.size else 5e-3
+    n_tol = 5e-3 * max(1.0, (0.2 / float(radii.min())) ** 2) if radii.size else 5e-3
     assert np.abs(fast["n"][m] - det["n"][m]).max() < n_tol
     assert np.array_equal(fast["material"][m], det["material"][m])
     # texture coordinates: the sphere's wrap at phi = +-pi maps u = 0 onto u = 1
