@@ -824,9 +824,20 @@ struct Onb {
 RTX_DEV Onb onb_from_w(V3 n) {
     Onb b;
     b.w = normalize(n);
+#if RTX_DET
     V3 a = (__builtin_fabsf(b.w.x) > 0.9f) ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f);
     b.v = normalize(cross(b.w, a));
     b.u = cross(b.w, b.v);
+#else
+    // Any orthonormal pair around w serves: the densities sampled in this basis (cosine lobe,
+    // cone towards a sphere) are symmetric about w.  Branch-free construction without the
+    // second normalisation (Duff et al., "Building an Orthonormal Basis, Revisited").
+    const float sign = __builtin_copysignf(1.0f, b.w.z);
+    const float a = -frcp(sign + b.w.z);
+    const float c = b.w.x * b.w.y * a;
+    b.u = v3(1.0f + sign * b.w.x * b.w.x * a, sign * c, -sign * b.w.x);
+    b.v = v3(c, sign + b.w.y * b.w.y * a, -b.w.y);
+#endif
     return b;
 }
 RTX_DEV V3 onb_local(const Onb& b, V3 a) {  // ONB.h:24-26

@@ -162,24 +162,43 @@ def test_bvh_and_linear_scan_agree_at_scale(gpu_ctx):
 
 
 def test_fast_mode_converges_to_cpu_ground_truth(gpu_ctx):
-    """Default (fast) mode: same estimator, arithmetic free to fuse / approximate.  At equal
-    spp its error against a 4096-spp CPU ground truth must equal the CPU tracer's own."""
+    """Default (fast) mode: same estimator, arithmetic and random stream free to differ.  Its
+    mean squared error against a 4096-spp CPU ground truth must equal the CPU tracer's at equal
+    spp.  One render's MSE scatters by +-8 % from seed to seed (fireflies), so the comparison is
+    over 24 seeds; the deterministic mode, which is the CPU tracer bit for bit (checked here on
+    two seeds), supplies the CPU side of the other 22."""
     from oracle import restate
 
     g = util.load_golden("ground_truth_cornell_160x90")
     gt = np.clip(g["mean"], 0, 1)
-    w, h, spp = 160, 90, 256
+    w, h, spp, seeds = 160, 90, 64, 24
     scene = api.HostScene("cornell", w, h)
     gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
-    fast, rays_fast = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_FAST, seed=5))
-    cpu = restate.render(scene, w, h, 0, spp, seed=5, threads=8)
-    rmse_fast = np.sqrt(np.mean((np.clip(fast / spp, 0, 1) - gt) ** 2))
-    rmse_cpu = np.sqrt(np.mean((np.clip(cpu["sum"] / spp, 0, 1) - gt) ** 2))
-    assert rmse_fast < 1.05 * rmse_cpu + 1e-4, (rmse_fast, rmse_cpu)
-    assert abs(rays_fast / cpu["rays"] - 1) < 0.01
-    # unbiased: means agree far below the per-pixel noise
-    assert abs(np.clip(fast / spp, 0, 1).mean() - gt.mean()) < 0.003
-    assert not np.isnan(fast).any()
+
+    def mse(img):
+        return float(np.mean((np.clip(img / spp, 0, 1) - gt) ** 2))
+
+    fast, det, rays_fast, rays_det = [], [], 0, 0
+    for seed in range(seeds):
+        img, r = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_FAST, seed=100 + seed))
+        assert not np.isnan(img).any()
+        fast.append(mse(img))
+        rays_fast += r
+        img, r = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_DETERMINISTIC, seed=100 + seed))
+        det.append(mse(img))
+        rays_det += r
+        if seed < 2:
+            cpu = restate.render(scene, w, h, 0, spp, seed=100 + seed, threads=8)
+            assert cpu["rays"] == r
+            assert abs(mse(cpu["sum"]) / det[-1] - 1) < 1e-3
+    fast, det = np.array(fast), np.array(det)
+    ratio = fast.mean() / det.mean()
+    sigma = np.sqrt(fast.var() / seeds + det.var() / seeds) / det.mean()
+    assert abs(ratio - 1) < max(4 * sigma, 0.05), (ratio, sigma)
+    assert abs(rays_fast / rays_det - 1) < 0.005
+    # unbiased: the mean over all seeds agrees far below the per-pixel noise
+    mean_fast, _ = gpu_ctx.render(gpu_ctx.params(w, h, 0, 4096, mode=api.RTX_MODE_FAST, seed=5))
+    assert abs(np.clip(mean_fast / 4096, 0, 1).mean() - gt.mean()) < 0.002
 
 
 def test_sample_ranges_and_accumulate_compose(gpu_ctx):
@@ -271,18 +290,25 @@ def test_fast_mode_hits_agree_with_golden_up_to_rounding(gpu_ctx, name, accel):
 
 
 def test_fast_mode_textured_scene_converges(gpu_ctx):
-    """Image textures in fast mode: same estimator as the CPU tracer on the same scene."""
+    """Image textures in fast mode: the estimator of the CPU tracer on the same scene (mean
+    squared error over 12 seeds against a CPU ground truth, scan and BVH)."""
     from oracle import restate
 
-    w, h, spp = 96, 54, 128
+    w, h, spp, seeds = 96, 54, 32, 12
     scene = api.HostScene("textured", w, h)
-    cpu = restate.render(scene, w, h, 1000, 4 * spp, seed=5, threads=8)["sum"] / (4 * spp)
+    gt = np.clip(restate.render(scene, w, h, 1000, 1024, seed=5, threads=8)["sum"] / 1024, 0, 1)
+
+    def mse(img):
+        return float(np.mean((np.clip(img / spp, 0, 1) - gt) ** 2))
+
     for accel in (api.RTX_ACCEL_LINEAR, api.RTX_ACCEL_BVH):
         gpu_ctx.upload(scene, accel)
-        fast, _ = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_FAST, seed=9))
-        det, _ = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_DETERMINISTIC, seed=9))
-        gt = np.clip(cpu, 0, 1)
-        rmse_fast = np.sqrt(np.mean((np.clip(fast / spp, 0, 1) - gt) ** 2))
-        rmse_det = np.sqrt(np.mean((np.clip(det / spp, 0, 1) - gt) ** 2))
-        assert rmse_fast < 1.08 * rmse_det + 1e-4, (rmse_fast, rmse_det)
-        assert abs(np.clip(fast / spp, 0, 1).mean() - gt.mean()) < 0.004
+        fast = np.array([mse(gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_FAST, seed=s))[0])
+                         for s in range(seeds)])
+        det = np.array([mse(gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_DETERMINISTIC, seed=s))[0])
+                        for s in range(seeds)])
+        ratio = fast.mean() / det.mean()
+        sigma = np.sqrt(fast.var() / seeds + det.var() / seeds) / det.mean()
+        assert abs(ratio - 1) < max(4 * sigma, 0.08), (accel, ratio, sigma)
+        big, _ = gpu_ctx.render(gpu_ctx.params(w, h, 0, 2048, mode=api.RTX_MODE_FAST, seed=9))
+        assert abs(np.clip(big / 2048, 0, 1).mean() - gt.mean()) < 0.003
