@@ -476,7 +476,8 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
         rtxd::Light& E = lights[l];
         E.a = s->light_a[l]; E.b = s->light_b[l]; E.c = s->light_c[l]; E.d = s->light_d[l]; E.e = s->light_e[l];
         E.kind = s->light_kind[l];
-        E.pad[0] = E.pad[1] = 0;
+        E.inv_area = E.kind <= RTX_LIGHT_RECT_YZ ? 1.0f / ((E.b - E.a) * (E.d - E.c)) : 0.0f;
+        E.pad = 0;
     }
     // one record per primitive with all the integrator needs after a hit
     std::vector<rtxd::PrimInfo> info(s->n_prims);

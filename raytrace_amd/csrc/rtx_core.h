@@ -942,6 +942,40 @@ RTX_DEV float light_pdf(const SceneView& sc, V3 o, V3 v) {
     return sum;
 }
 
+#if !RTX_DET
+// The same densities with the algebra folded (fast mode): len2 = |v|^2 and inv_len = 1/|v| come
+// from the caller, which needs them for the cosine density too.
+//   rect (Rect.cpp:36-48): t^2 |v|^2 / (|v.y| / |v| * area) with t = (k - o.y) / v.y
+//   sphere (Sphere.cpp:38-50): hit iff the far root lies beyond t_min; 1 / (2 pi (1 - cos_max))
+RTX_DEV float light_pdf_one_fast(const Light& E, V3 o, V3 v, float len2, float inv_len) {
+    if (E.kind == RTX_LIGHT_RECT_XZ) {
+        const float inv_vy = frcp(v.y);
+        const float t = (E.e - o.y) * inv_vy;
+        const float x = __builtin_fmaf(t, v.x, o.x), z = __builtin_fmaf(t, v.z, o.z);
+        const bool ok = (t >= kTMin) & (x >= E.a) & (x <= E.b) & (z >= E.c) & (z <= E.d);
+        const float pdf = ((t * t) * (len2 * len2)) * ((inv_len * __builtin_fabsf(inv_vy)) * E.inv_area);
+        return ok ? pdf : 0.0f;
+    }
+    if (E.kind == RTX_LIGHT_SPHERE) {
+        const V3 oc = o - v3(E.a, E.b, E.c);
+        const float h = dot(oc, v), dd = dot(oc, oc), r2 = E.d * E.d;
+        const float D = h * h - len2 * (dd - r2);
+        const bool ok = (D > 0.0f) & (fsqrt(D) - h > kTMin * len2);
+        const float rr = dd < r2 ? dd : r2;
+        const float cos_theta_max = fsqrt(1.0f - rr * frcp(dd));
+        return ok ? frcp(kPi2 * (1.0f - cos_theta_max)) : 0.0f;
+    }
+    return 0.0f;
+}
+
+RTX_DEV float light_pdf_fast(const SceneView& sc, V3 o, V3 v, float len2, float inv_len) {
+    if (!sc.light_is_list) return light_pdf_one_fast(load_uniform(sc.lights, 0u), o, v, len2, inv_len);
+    float sum = 0.0f;
+    for (uint32_t k = 0; k < sc.n_lights; ++k) sum += light_pdf_one_fast(load_uniform(sc.lights, k), o, v, len2, inv_len);
+    return sum * frcp((float)sc.n_lights);
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // reflect / refract / schlick, Util.h:56-76
 // ---------------------------------------------------------------------------
@@ -997,6 +1031,21 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
     if (mat_kind == RTX_MAT_LAMBERTIAN) {
         V3 albedo = surface_color(sc, rec);  // Lambertian.cpp:17
         const V3 dir = sample_direction(sc, rec.p, rec.n, ps.rng);
+#if !RTX_DET
+        {   // the same estimator with 1 / |dir| shared between the densities
+            const float len2 = dot(dir, dir), inv_len = finvsqrt(len2);
+            const float pdf0 = light_pdf_fast(sc, rec.p, dir, len2, inv_len);
+            const float cosine = dot(dir, rec.n) * inv_len;
+            const float pdf1 = (cosine > 0.0f ? cosine : 0.0f) * (1.0f / kPi);  // = the scattering pdf
+            const float pdf_value = 0.5f * pdf0 + 0.5f * pdf1;
+            if (!(pdf_value > 0.0f)) return true;
+            ps.T = vmul(albedo, ps.T) * (pdf1 * frcp(pdf_value));
+            ps.o = rec.p;
+            ps.d = dir;
+            ps.depth += 1;
+            return false;
+        }
+#endif
         // MixturePdf::value, MixturePdf.h:9-13
         float pdf0 = light_pdf(sc, rec.p, dir);
         float cosine = dot(normalize(dir), rec.n);  // CosinePdf.cpp:7

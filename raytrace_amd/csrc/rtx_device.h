@@ -105,7 +105,8 @@ struct alignas(32) Texture {
 struct alignas(32) Light {
     float a, b, c, d, e;  // as Prim
     uint32_t kind;        // RTX_LIGHT_*
-    uint32_t pad[2];
+    float inv_area;       // rect: 1 / ((x1 - x0) * (y1 - y0)), used by the fast-mode pdf
+    uint32_t pad;
 };
 
 // BVH over top-level items (a bare primitive, or one transformed instance such as a Box under
