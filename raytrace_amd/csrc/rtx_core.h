@@ -555,10 +555,10 @@ RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, boo
                 float root = fsqrt(D);  // NaN for a negative discriminant: every test below fails
                 float ta = (-h - root) * inv_a;
                 float tb = (-h + root) * inv_a;
-                bool oka = (D > 0.0f) & (ta < closest) & (ta > t0);
-                bool okb = (D > 0.0f) & (tb < closest) & (tb > t0);
-                float t = oka ? ta : tb;
-                bool ok = oka | okb;
+                // ta <= tb: the near root if it lies beyond t0, else the far one; a near root
+                // at or beyond `closest` rules the far one out too (Sphere.cpp:14-31)
+                float t = ta > t0 ? ta : tb;
+                bool ok = (D > 0.0f) & (t > t0) & (t < closest);
                 closest = ok ? t : closest;
                 best = ok ? pos : best;
             }
