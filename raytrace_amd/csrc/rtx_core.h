@@ -1245,6 +1245,177 @@ __global__ void __launch_bounds__(RTX_BLOCK, kBvh ? RTX_TRACE_WAVES_BVH : RTX_TR
     }
 }
 
+#if !RTX_DET
+// BVH scenes, fast mode: the same pool of (pixel, sample) items per wave, but traversal and
+// shading are decoupled.  A lane is idle, traversing, or holds a finished nearest-hit query;
+// each iteration of the wave performs ONE traversal step (a node, or a leaf) for the lanes
+// that are traversing (RTX_WALK_STEPS of them between two looks at the wave's state), and the
+// shading / camera-ray stage only runs once kShadeBatch lanes wait for it (or nothing is left
+// to traverse).  Traversal lengths of incoherent rays differ
+// by an order of magnitude: in trace_kernel every lane waits for the longest of the wave's
+// 64 queries before any of them is shaded, here a lane that is done is refilled while the
+// others walk on, and the scattering code runs on a well-filled wave.
+#ifndef RTX_SHADE_BATCH
+#define RTX_SHADE_BATCH 32  // measured 16 .. 56: 32 best on both BVH scenes
+#endif
+#ifndef RTX_WALK_STEPS
+#define RTX_WALK_STEPS 16   // traversal steps between two looks at the wave's state (1 .. 32 measured)
+#endif
+constexpr uint32_t kShadeBatch = RTX_SHADE_BATCH;
+
+template <bool kUnused>
+__global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES_BVH) trace_bvh_kernel(const TraceArgs a) {
+    __shared__ float s_acc[RTX_BLOCK / 64][3][64];
+    __shared__ uint32_t s_stack[kBvhStack][RTX_BLOCK];
+    const SceneView& sc = a.scene;
+    const uint32_t tid = threadIdx.x, lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t twl = a.tile_w_log2, pixl = a.tile_w_log2 + a.tile_h_log2;
+    const uint32_t tile_w = 1u << twl, tile_h = 1u << a.tile_h_log2, pix_mask = (1u << pixl) - 1u;
+    constexpr uint32_t kSide = RTX_BLOCK == 256 ? 2u : 1u;
+    const uint32_t tiles_x = (a.width + kSide * tile_w - 1u) / (kSide * tile_w);
+    const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const uint32_t x0 = (kSide * bx + (wave & (kSide - 1u))) * tile_w;
+    const uint32_t y0 = (kSide * by + (wave >> (kSide - 1u))) * tile_h;
+    if (x0 >= a.width || y0 >= a.height) return;  // wave-uniform
+    const uint32_t tw = min(tile_w, a.width - x0), th = min(tile_h, a.height - y0);
+    s_acc[wave][0][lane] = 0.0f;
+    s_acc[wave][1][lane] = 0.0f;
+    s_acc[wave][2][lane] = 0.0f;
+
+    const uint32_t total = a.spp_count << pixl;
+    uint32_t next = 0;
+    uint32_t rays = 0, segs = 0, item = 0;
+    enum : uint32_t { kIdle = 0u, kWalk = 1u, kDoneWalk = 2u, kNewRay = 3u };
+    uint32_t phase = kIdle;
+    PathState ps;
+    ps.o = ps.d = ps.T = v3(0.0f, 0.0f, 0.0f);
+    ps.depth = 0;
+    ps.rng.state = 0;
+    ps.rng.inc = 1;
+    // the query in flight
+    constexpr uint32_t kDone = 0xffffffffu;
+    uint32_t ref = kDone, sp = 0, best = kNone;
+    float closest = kFltMax;
+    V3 inv = v3(0.0f, 0.0f, 0.0f), noi = inv;
+    const float fnx = (float)a.width, fny = (float)a.height;
+
+    for (;;) {
+        const unsigned long long walking = __ballot(phase == kWalk);
+        const uint32_t n_done = (uint32_t)__popcll(__ballot(phase == kDoneWalk));
+        const unsigned long long idle = __ballot(phase == kIdle);
+        const bool pool_left = next < total;
+        const uint32_t waiting = n_done + (pool_left ? (uint32_t)__popcll(idle) : 0u);
+        if (waiting != 0u && (walking == 0ull || waiting >= kShadeBatch)) {
+            if (phase == kDoneWalk) {  // Scene::color for the finished query
+                HitRec rec;
+                const bool hit = best != kNone;
+                if (hit) finish_scan_hit<true>(sc, best, closest, ps.o, ps.d, false, rec);
+                ++segs;
+                V3 L;
+                if (shade(sc, a.max_depth, hit, rec, ps, L)) {
+                    const uint32_t slot = item & pix_mask;
+                    atomicAdd(&s_acc[wave][0][slot], L.x);  // Scene.cpp:148
+                    atomicAdd(&s_acc[wave][1][slot], L.y);
+                    atomicAdd(&s_acc[wave][2][slot], L.z);
+                    rays += segs;
+                    phase = kIdle;
+                } else {
+                    phase = kNewRay;
+                }
+            }
+            const unsigned long long want = __ballot(phase == kIdle);
+            if (want != 0ull && next < total) {  // idle lanes draw the next items of the pool
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                const uint32_t mine = next + rank;
+                next += (uint32_t)__popcll(want);
+                if (phase == kIdle && mine < total) {
+                    const uint32_t slot = mine & pix_mask;
+                    const uint32_t sx = slot & (tile_w - 1u), sy = slot >> twl;
+                    if (sx < tw && sy < th) {
+                        item = mine;
+                        const uint32_t i = x0 + sx, j = y0 + sy;
+                        rng_init(&ps.rng, j * a.width + i, a.spp_begin + (mine >> pixl), a.seed);
+                        float u = fdiv((float)i + rng_nextf(&ps.rng), fnx);  // Scene.cpp:145-146
+                        float v = fdiv((float)j + rng_nextf(&ps.rng), fny);
+                        ps.o = v3(sc.cam_origin);  // Camera::getRay, Camera.h:24-26
+                        ps.d = ((v3(sc.cam_ll) + v3(sc.cam_u) * u) + v3(sc.cam_v) * v) - ps.o;
+                        ps.T = v3(1.0f, 1.0f, 1.0f);
+                        ps.depth = 0;
+                        segs = 0;
+                        phase = kNewRay;
+                    }
+                }
+            }
+            if (phase == kNewRay) {  // start the nearest-hit query of the new segment
+                constexpr float kBig = 1.0e18f;  // see hit_bvh
+                inv = v3(__builtin_amdgcn_fmed3f(frcp(ps.d.x), -kBig, kBig), __builtin_amdgcn_fmed3f(frcp(ps.d.y), -kBig, kBig),
+                         __builtin_amdgcn_fmed3f(frcp(ps.d.z), -kBig, kBig));
+                noi = v3(-ps.o.x * inv.x, -ps.o.y * inv.y, -ps.o.z * inv.z);
+                ref = 0u;  // root
+                sp = 0u;
+                closest = kFltMax;
+                best = kNone;
+                phase = kWalk;
+            }
+        }
+        if (__ballot(phase != kIdle) == 0ull) {
+            if (next >= total) break;  // pool spent, nothing in flight
+            continue;                  // this draw fell outside the image (ragged tile): draw again
+        }
+#pragma unroll 1
+        for (int step = 0; step < RTX_WALK_STEPS; ++step)
+        if (phase == kWalk) {  // one step: a node, or a leaf
+            if (!(ref & kBvhLeaf)) {
+                const BvhNode N = sc.bvh[ref];
+                float n0, n1;
+                const bool h0 = slab(N.lo0, N.hi0, inv, noi, kTMin, closest, n0);
+                const bool h1 = slab(N.lo1, N.hi1, inv, noi, kTMin, closest, n1);
+                if (h0 & h1) {
+                    const bool first0 = n0 <= n1;
+                    if (sp < (uint32_t)kBvhStack) s_stack[sp][tid] = first0 ? N.child1 : N.child0;
+                    ++sp;
+                    ref = first0 ? N.child0 : N.child1;
+                } else if (h0 | h1) {
+                    ref = h0 ? N.child0 : N.child1;
+                } else {
+                    ref = pop_ref(s_stack, sp, tid);
+                }
+            } else {
+                const uint32_t first = ref & kBvhLeafFirst, count = (ref >> kBvhLeafCountShift) & 15u;
+                for (uint32_t k = 0; k < count; ++k)
+                    fast_leaf_item(sc, sc.bvh_fast[first + k], ps.o, ps.d, inv, noi, kTMin, closest, best);
+                ref = pop_ref(s_stack, sp, tid);
+            }
+            if (ref == kDone) phase = kDoneWalk;
+        }
+    }
+
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t sx = lane & (tile_w - 1u), sy = lane >> twl;
+    if (a.accum && sx < tw && sy < th) {
+        const uint32_t i = x0 + sx, j = y0 + sy;
+        float* out = a.accum + ((size_t)(a.height - 1u - j) * a.width + i) * 3u;  // Scene.cpp:151
+        const float r = s_acc[wave][0][lane], g = s_acc[wave][1][lane], b = s_acc[wave][2][lane];
+        if (a.accumulate) {
+            out[0] += r;
+            out[1] += g;
+            out[2] += b;
+        } else {
+            out[0] = r;
+            out[1] = g;
+            out[2] = b;
+        }
+    }
+    if (a.rays) {
+        uint32_t r = rays;
+        for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
+        if (lane == 0u) atomicAdd(a.rays, (unsigned long long)r);
+    }
+}
+#endif
+
 // Shape::hit of the world for arbitrary rays.
 template <bool kBvh>
 __global__ void __launch_bounds__(256) hit_kernel(const HitArgs a) {
