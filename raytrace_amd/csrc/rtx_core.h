@@ -8,7 +8,9 @@
 //       performs it, so hit / miss decisions, sampled directions and hit points
 //       are bit-identical to the reference fed the same random stream.
 //   RTX_DET = 0  (rtx_kernels_fast.hip, contraction on, v_rcp / v_rsq / v_sin):
-//       same algorithm and random stream, arithmetic free to fuse and approximate.
+//       the same estimator, with arithmetic free to fuse and approximate, a lighter
+//       random stream, the scan re-ordered by primitive kind, boxes by slab tests and
+//       the densities algebraically folded; statistically equal, not bit-equal.
 //
 // Reference citations are relative to Raytrace_C++/Src.
 #pragma once
@@ -32,7 +34,7 @@
 
 #define RTX_DEV __device__ __forceinline__
 
-// threads per block of the trace kernel: 64 (one wave, one 8x8 tile) or 256 (2x2 waves)
+// threads per block of the trace kernels: 256 (2x2 waves, each with its own pixel tile) or 64
 #ifndef RTX_BLOCK
 #define RTX_BLOCK 256
 #endif
