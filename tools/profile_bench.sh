@@ -3,7 +3,7 @@
 #   bash tools/profile_bench.sh <tag>
 # Writes gpurun_out/prof_<tag>/... ; copy the summaries you want judged into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-run}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

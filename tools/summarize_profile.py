@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 result databases written by tools/profile_bench.sh into one text
 summary (per-kernel timing from the --kernel-trace --stats run, per-kernel PMC sums from
-the --pmc runs, and the derived figures quoted in DESIGN.md).
+the --pmc runs, and the figures derived from them).
 
     python tools/summarize_profile.py gpurun_out/prof_<tag> > profiles/<name>.txt
 """
