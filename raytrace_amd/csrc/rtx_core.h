@@ -1264,6 +1264,10 @@ __global__ void __launch_bounds__(RTX_BLOCK, kBvh ? RTX_TRACE_WAVES_BVH : RTX_TR
 #define RTX_WALK_STEPS 16   // traversal steps between two looks at the wave's state (1 .. 32 measured)
 #endif
 constexpr uint32_t kShadeBatch = RTX_SHADE_BATCH;
+#ifndef RTX_LEAF_BATCH
+#define RTX_LEAF_BATCH 16
+#endif
+constexpr uint32_t kLeafBatch = RTX_LEAF_BATCH;
 
 template <bool kUnused>
 __global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES_BVH) trace_bvh_kernel(const TraceArgs a) {
@@ -1367,9 +1371,16 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES_BVH) trace_bvh_kern
             continue;                  // this draw fell outside the image (ragged tile): draw again
         }
 #pragma unroll 1
-        for (int step = 0; step < RTX_WALK_STEPS; ++step)
-        if (phase == kWalk) {  // one step: a node, or a leaf
-            if (!(ref & kBvhLeaf)) {
+        for (int step = 0; step < RTX_WALK_STEPS; ++step) {
+            // lanes at an inner node take one step down; lanes that reached a leaf hold it until
+            // kLeafBatch of them have one (or nobody is left at a node), so that the leaf code
+            // - four record types, each its own branch - runs on a fuller wave
+            const bool at_leaf = phase == kWalk && (ref & kBvhLeaf) != 0u;
+            const bool at_node = phase == kWalk && !at_leaf;
+            const unsigned long long nodes = __ballot(at_node);
+            const uint32_t n_leaves = (uint32_t)__popcll(__ballot(at_leaf));
+            if (nodes == 0ull && n_leaves == 0u) break;
+            if (at_node) {
                 const BvhNode N = sc.bvh[ref];
                 float n0, n1;
                 const bool h0 = slab(N.lo0, N.hi0, inv, noi, kTMin, closest, n0);
@@ -1384,13 +1395,17 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES_BVH) trace_bvh_kern
                 } else {
                     ref = pop_ref(s_stack, sp, tid);
                 }
-            } else {
-                const uint32_t first = ref & kBvhLeafFirst, count = (ref >> kBvhLeafCountShift) & 15u;
-                for (uint32_t k = 0; k < count; ++k)
-                    fast_leaf_item(sc, sc.bvh_fast[first + k], ps.o, ps.d, inv, noi, kTMin, closest, best);
-                ref = pop_ref(s_stack, sp, tid);
+                if (ref == kDone) phase = kDoneWalk;
             }
-            if (ref == kDone) phase = kDoneWalk;
+            if (n_leaves >= kLeafBatch || (nodes == 0ull && n_leaves != 0u)) {
+                if (at_leaf) {
+                    const uint32_t first = ref & kBvhLeafFirst, count = (ref >> kBvhLeafCountShift) & 15u;
+                    for (uint32_t k = 0; k < count; ++k)
+                        fast_leaf_item(sc, sc.bvh_fast[first + k], ps.o, ps.d, inv, noi, kTMin, closest, best);
+                    ref = pop_ref(s_stack, sp, tid);
+                    if (ref == kDone) phase = kDoneWalk;
+                }
+            }
         }
     }
 
