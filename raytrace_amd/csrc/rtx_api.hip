@@ -362,6 +362,8 @@ int check_params(const RtxContext* ctx, const RtxParams* p) {
     if (p->mode > RTX_MODE_DETERMINISTIC) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown mode");
     if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull)
         return fail(RTX_ERR_INVALID_ARGUMENT, "sample range overflows 32 bits");
+    if (p->spp_count > (1u << 28))  // a wave's item counter (pixels of its tile x samples) is 32 bits
+        return fail(RTX_ERR_TOO_LARGE, "more than 2^28 samples per pixel in one call: split the range");
     return RTX_OK;
 }
 
