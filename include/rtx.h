@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 2u
+#define RTX_ABI_VERSION 3u
 
 typedef enum RtxStatus {
     RTX_OK = 0,
@@ -47,6 +47,8 @@ enum { RTX_STEP_TRANSLATE = 0, RTX_STEP_ROTATE = 1 };
 enum { RTX_MAT_LAMBERTIAN = 0, RTX_MAT_METAL = 1, RTX_MAT_DIELECTRIC = 2, RTX_MAT_DIFFUSE_LIGHT = 3 };
 /* Texture kinds (ColorTexture.h, CheckerTexture.h, ImageTexture.h). */
 enum { RTX_TEX_COLOR = 0, RTX_TEX_CHECKER = 1, RTX_TEX_IMAGE = 2 };
+/* What a ray that hits nothing returns (Scene::background / Scene::backgroundSky, Scene.h:20-28). */
+enum { RTX_BACKGROUND_CONSTANT = 0, RTX_BACKGROUND_SKY = 1 };
 /* Acceleration structure choice for rtx_upload_scene(). */
 enum { RTX_ACCEL_AUTO = 0, RTX_ACCEL_LINEAR = 1, RTX_ACCEL_BVH = 2 };
 /* Arithmetic modes of a render. */
@@ -108,8 +110,11 @@ typedef struct RtxScene {
     uint64_t n_texel_bytes;        /* may be 0 */
     const uint8_t* texels;         /* 8-bit RGB, rows top-down, 3 bytes per texel, no padding */
 
-    /* light shape handed to Scene::color (Scene.cpp:113) */
-    uint32_t n_lights;             /* >= 1 */
+    /* light shape handed to Scene::color (Scene.cpp:113).  n_lights == 0 (an extension: the
+     * reference's color() always takes a light) means there is none: a diffuse bounce is then
+     * sampled from the material's own pdf alone, srec.pdf of Lambertian.cpp:19, with no
+     * mixture and no extra draw. */
+    uint32_t n_lights;
     uint32_t light_is_list;        /* 1: a ShapeList (one extra draw picks the entry,
                                       ShapeList.cpp:28-35); 0: a single bare shape */
     const uint32_t* light_kind;    /* RTX_LIGHT_* */
@@ -126,6 +131,7 @@ typedef struct RtxScene {
     float cam_v[3];
 
     float background[3];           /* Scene::background (Scene.h:20-22) */
+    uint32_t background_mode;      /* RTX_BACKGROUND_*; SKY ignores background[] */
 } RtxScene;
 
 typedef struct RtxParams {

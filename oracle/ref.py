@@ -118,3 +118,24 @@ def write_bmp(path, rgb8):
     a = np.ascontiguousarray(rgb8, np.uint8)
     h, w, _ = a.shape
     return lib.ref_write_bmp(path.encode(), w, h, a.ctypes.data)
+
+
+def background_sky(dirs):
+    """Scene::backgroundSky (Scene.h:24-28) of n directions."""
+    lib = load()
+    d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+    out = np.zeros_like(d)
+    lib.ref_background_sky(C.c_int(d.shape[0]), C.c_void_p(d.ctypes.data), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def cosine_pdf(normals, seed=0):
+    """CosinePdf::generate / value (CosinePdf.cpp:6-20) around n normals; entry k draws from the
+    stream of (pixel k, sample 0, seed).  Returns (directions, values)."""
+    lib = load()
+    nn = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    dirs = np.zeros_like(nn)
+    vals = np.zeros(nn.shape[0], np.float32)
+    lib.ref_cosine_pdf(C.c_int(nn.shape[0]), C.c_void_p(nn.ctypes.data), C.c_uint64(seed),
+                            C.c_void_p(dirs.ctypes.data), C.c_void_p(vals.ctypes.data))
+    return dirs, vals

@@ -29,6 +29,7 @@
 #include "DiffuseLight.h"
 #include "ColorTexture.h"
 #include "CheckerTexture.h"
+#include "CosinePdf.h"
 #include <stb_image.h> /* declarations only, for ImageTexture.h:9 */
 #include "ImageTexture.h"
 #include <stb_image_write.h> /* declarations only; the implementation is compiled in Scene.cpp:3-6 */
@@ -99,6 +100,12 @@ void* ref_scene_create(const char* name, int w, int h) {
     } else {
         SceneParts parts;
         if (!make_scene(name, w, h, parts)) return nullptr;
+        if (parts.sky || !parts.light) {  // the reference's color() cannot render these
+            delete parts.camera;
+            delete parts.world;
+            delete parts.light;
+            return nullptr;
+        }
         rs->own_camera.reset(parts.camera);
         rs->own_world.reset(parts.world);
         rs->own_light.reset(parts.light);
@@ -253,4 +260,34 @@ int ref_write_bmp(const char* path, int w, int h, const uint8_t* rgb) {
     return stbi_write_bmp(path, w, h, 3, rgb);
 }
 
+
+/* Scene::backgroundSky (Scene.h:24-28) of n directions: the reference defines the gradient but
+ * its color() never calls it, so it is pinned function by function. */
+int ref_background_sky(int n, const float* dirs, float* out) {
+    Scene scene("unused.bmp", 4, 4, 1);
+    for (int k = 0; k < n; ++k) {
+        Vector3 c = scene.backgroundSky(Vector3(dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]));
+        out[3 * k] = c.getX();
+        out[3 * k + 1] = c.getY();
+        out[3 * k + 2] = c.getZ();
+    }
+    return 0;
+}
+
+/* CosinePdf::generate / ::value (CosinePdf.cpp:6-20) around n normals; entry k draws from the
+ * stream of (pixel k, sample 0, seed). */
+int ref_cosine_pdf(int n, const float* normals, uint64_t seed, float* dirs, float* values) {
+    CosinePdf pdf;
+    for (int k = 0; k < n; ++k) {
+        HitRec h;
+        h.n = Vector3(normals[3 * k], normals[3 * k + 1], normals[3 * k + 2]);
+        rtx_rng_init(&g_rt_rng, uint32_t(k), 0u, seed);
+        Vector3 d = pdf.generate(h);
+        dirs[3 * k] = d.getX();
+        dirs[3 * k + 1] = d.getY();
+        dirs[3 * k + 2] = d.getZ();
+        values[k] = pdf.value(h, d);
+    }
+    return 0;
+}
 }  // extern "C"

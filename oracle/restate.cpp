@@ -574,11 +574,39 @@ public:
         return light_entry_random((uint32_t)index, o);
     }
 
+    // Scene::background (Scene.h:20-22) or Scene::backgroundSky (Scene.h:24-28; lerp, vec_aos.h:92-95)
+    Vec<F> background(const Vec<F>& d) const {
+        if (sc.background_mode != RTX_BACKGROUND_SKY) return Vec<F>(sc.background[0], sc.background[1], sc.background[2]);
+        Vec<F> v = normalize(d);
+        F t = F(0.5f) * (v.y + F(1.0f));
+        Vec<F> a(1.0f, 1.0f, 1.0f), b(0.5f, 0.7f, 1.0f);
+        return a + (b - a) * t;
+    }
+
+    // CosinePdf::generate (CosinePdf.cpp:16-20) with random_cosine_direction (Util.h:86-94)
+    Vec<F> cosine_generate(const Vec<F>& n) {
+        Basis uvw = basis_from_w(n);
+        F r1 = draw();
+        F r2 = draw();
+        F z = f_sqrt(F(1.0f) - r2);
+        F phi = F(kPI2) * r1;
+        F sn, cs;
+        f_sincos(phi, sn, cs);
+        F x = cs * f_sqrt(r2);
+        F y = sn * f_sqrt(r2);
+        return basis_local(uvw, Vec<F>(x, y, z));
+    }
+
+    // CosinePdf::value, CosinePdf.cpp:6-14
+    F cosine_value(const Vec<F>& n, const Vec<F>& dir) const {
+        F cosine = dot(normalize(dir), n);
+        return cosine > F(0.0f) ? cosine / F(kPI) : F(0.0f);
+    }
+
     // Scene::color, Scene.cpp:103-132
     Vec<F> color(const Vec<F>& o, const Vec<F>& d, int depth) {
         Hit<F> rec;
-        if (!world_hit(o, d, F(0.001f), F(FLT_MAX), rec))
-            return Vec<F>(sc.background[0], sc.background[1], sc.background[2]);
+        if (!world_hit(o, d, F(0.001f), F(FLT_MAX), rec)) return background(d);
         const uint32_t m = rec.material;
         const uint32_t kind = sc.mat_kind[m];
         // Material::emitted: Material.h:10, DiffuseLight.h:21-28
@@ -641,25 +669,22 @@ public:
             default: {  // Lambertian.cpp:16-25 + Scene.cpp:112-125
                 Vec<F> albedo = texture_value(sc.mat_texture[m], rec);
                 Vec<F> dir;
-                if (draw() < F(0.5f)) {  // MixturePdf::generate, MixturePdf.h:15-22
-                    dir = light_random(rec.p);
-                } else {  // CosinePdf::generate (CosinePdf.cpp:16-20), random_cosine_direction (Util.h:86-94)
-                    Basis uvw = basis_from_w(rec.n);
-                    F r1 = draw();
-                    F r2 = draw();
-                    F z = f_sqrt(F(1.0f) - r2);
-                    F phi = F(kPI2) * r1;
-                    F sn, cs;
-                    f_sincos(phi, sn, cs);
-                    F x = cs * f_sqrt(r2);
-                    F y = sn * f_sqrt(r2);
-                    dir = basis_local(uvw, Vec<F>(x, y, z));
+                F pdf_value;
+                if (sc.n_lights == 0) {
+                    // no light shape (not expressible in the reference, whose color() always mixes
+                    // with a ShapePdf): the material's own pdf, srec.pdf of Lambertian.cpp:19, alone
+                    dir = cosine_generate(rec.n);
+                    pdf_value = cosine_value(rec.n, dir);
+                } else {
+                    if (draw() < F(0.5f))  // MixturePdf::generate, MixturePdf.h:15-22
+                        dir = light_random(rec.p);
+                    else
+                        dir = cosine_generate(rec.n);
+                    // MixturePdf::value, MixturePdf.h:9-13
+                    F pdf0 = light_pdf(rec.p, dir);
+                    F pdf1 = cosine_value(rec.n, dir);
+                    pdf_value = F(0.5f) * pdf0 + F(0.5f) * pdf1;
                 }
-                // MixturePdf::value, MixturePdf.h:9-13
-                F pdf0 = light_pdf(rec.p, dir);
-                F cosine = dot(normalize(dir), rec.n);  // CosinePdf::value, CosinePdf.cpp:6-14
-                F pdf1 = cosine > F(0.0f) ? cosine / F(kPI) : F(0.0f);
-                F pdf_value = F(0.5f) * pdf0 + F(0.5f) * pdf1;
                 if (!(pdf_value > F(0.0f))) return emitted;
                 F c2 = dot(rec.n, normalize(dir));  // Lambertian::scattering_pdf, Lambertian.cpp:23-25
                 F spdf = (c2 < F(0.0f) ? F(0.0f) : c2) / F(kPI);
@@ -809,4 +834,33 @@ void restate_image_write(int n, const float* rgb, uint8_t* out) {
     }
 }
 
+
+/* The two pieces of the no-light / sky extension the reference does contain, for function-level
+ * pinning: Scene::backgroundSky (Scene.h:24-28) and CosinePdf::generate / value
+ * (CosinePdf.cpp:6-20), entry k drawing from the stream of (pixel k, sample 0, seed). */
+int restate_background_sky(int n, const float* dirs, float* out) {
+    RtxScene sc;
+    std::memset(&sc, 0, sizeof sc);
+    sc.background_mode = RTX_BACKGROUND_SKY;
+    Tracer<float> tr(sc, 50);
+    for (int k = 0; k < n; ++k) {
+        Vec<float> c = tr.background(Vec<float>(dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]));
+        out[3 * k] = c.x; out[3 * k + 1] = c.y; out[3 * k + 2] = c.z;
+    }
+    return 0;
+}
+
+int restate_cosine_pdf(int n, const float* normals, uint64_t seed, float* dirs, float* values) {
+    RtxScene sc;
+    std::memset(&sc, 0, sizeof sc);
+    Tracer<float> tr(sc, 50);
+    for (int k = 0; k < n; ++k) {
+        Vec<float> nn(normals[3 * k], normals[3 * k + 1], normals[3 * k + 2]);
+        rtx_rng_init(&tr.rng, uint32_t(k), 0u, seed);
+        Vec<float> d = tr.cosine_generate(nn);
+        dirs[3 * k] = d.x; dirs[3 * k + 1] = d.y; dirs[3 * k + 2] = d.z;
+        values[k] = tr.cosine_value(nn, d);
+    }
+    return 0;
+}
 }  // extern "C"

@@ -15,12 +15,13 @@ import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
-RTX_ABI_VERSION = 2
+RTX_ABI_VERSION = 3
 RTX_ACCEL_AUTO, RTX_ACCEL_LINEAR, RTX_ACCEL_BVH = 0, 1, 2
 RTX_MODE_FAST, RTX_MODE_DETERMINISTIC = 0, 1
 RTX_PRIM_RECT_XY, RTX_PRIM_RECT_XZ, RTX_PRIM_RECT_YZ, RTX_PRIM_SPHERE = 0, 1, 2, 3
 RTX_MAT_LAMBERTIAN, RTX_MAT_METAL, RTX_MAT_DIELECTRIC, RTX_MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
 RTX_TEX_COLOR, RTX_TEX_CHECKER, RTX_TEX_IMAGE = 0, 1, 2
+RTX_BACKGROUND_CONSTANT, RTX_BACKGROUND_SKY = 0, 1
 RTX_OK = 0
 RTX_ERR_INVALID_ARGUMENT, RTX_ERR_NO_DEVICE, RTX_ERR_HIP = -1, -2, -3
 RTX_ERR_NO_SCENE, RTX_ERR_UNSUPPORTED, RTX_ERR_TOO_LARGE = -4, -5, -6
@@ -57,6 +58,7 @@ class RtxScene(C.Structure):
         ("cam_origin", C.c_float * 3), ("cam_ll", C.c_float * 3),
         ("cam_u", C.c_float * 3), ("cam_v", C.c_float * 3),
         ("background", C.c_float * 3),
+        ("background_mode", C.c_uint32),
     ]
 
 
@@ -246,6 +248,7 @@ class HostScene:
         for name in ("cam_origin", "cam_ll", "cam_u", "cam_v", "background"):
             out[name] = np.array(list(getattr(s, name)), np.float32)
         out["light_is_list"] = np.array([s.light_is_list], np.uint32)
+        out["background_mode"] = np.array([s.background_mode], np.uint32)
         out["texels"] = _as_np(s.texels, int(s.n_texel_bytes), np.uint8)
         return out
 

@@ -95,10 +95,9 @@ int check_scene(const RtxScene* s) {
     if (s->abi_version != RTX_ABI_VERSION)
         return fail(RTX_ERR_INVALID_ARGUMENT, "RtxScene.abi_version does not match this library");
     if (s->n_prims == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "scene has no primitives");
-    if (s->n_lights == 0)
-        return fail(RTX_ERR_INVALID_ARGUMENT,
-                    "light list is empty (the reference indexes m_list[0] of an empty list, "
-                    "ShapeList.cpp:28-35)");
+    if (s->background_mode > RTX_BACKGROUND_SKY) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown background_mode");
+    if (s->n_lights && (!s->light_kind || !s->light_a || !s->light_b || !s->light_c || !s->light_d || !s->light_e))
+        return fail(RTX_ERR_INVALID_ARGUMENT, "a light array is null");
     if (s->n_chains == 0 || !s->chain_begin)
         return fail(RTX_ERR_INVALID_ARGUMENT, "chain table missing (chain 0 must exist and be empty)");
     if (s->chain_begin[0] != 0 || s->chain_begin[1] != 0)
@@ -119,8 +118,6 @@ int check_scene(const RtxScene* s) {
                           !s->tex_offset))
         return fail(RTX_ERR_INVALID_ARGUMENT, "a texture array is null");
     if (s->n_texel_bytes && !s->texels) return fail(RTX_ERR_INVALID_ARGUMENT, "texels is null");
-    if (!s->light_kind || !s->light_a || !s->light_b || !s->light_c || !s->light_d || !s->light_e)
-        return fail(RTX_ERR_INVALID_ARGUMENT, "a light array is null");
     for (uint32_t p = 0; p < s->n_prims; ++p) {
         if (s->prim_kind[p] > RTX_PRIM_SPHERE) return fail(RTX_ERR_INVALID_ARGUMENT, "bad prim_kind");
         if (s->prim_material[p] >= s->n_materials)
@@ -148,7 +145,9 @@ int check_scene(const RtxScene* s) {
     for (uint32_t l = 0; l < s->n_lights; ++l)
         if (s->light_kind[l] > RTX_LIGHT_OTHER) return fail(RTX_ERR_INVALID_ARGUMENT, "bad light_kind");
     if (!s->light_is_list && s->n_lights != 1)
-        return fail(RTX_ERR_INVALID_ARGUMENT, "a bare (non-list) light shape must have exactly one entry");
+        return fail(RTX_ERR_INVALID_ARGUMENT,
+                    "a bare (non-list) light shape must have exactly one entry (no light at all: n_lights = 0 "
+                    "with light_is_list = 1)");
     return RTX_OK;
 }
 
@@ -570,6 +569,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     std::memcpy(v.cam_u, s->cam_u, sizeof v.cam_u);
     std::memcpy(v.cam_v, s->cam_v, sizeof v.cam_v);
     std::memcpy(v.background, s->background, sizeof v.background);
+    v.background_mode = s->background_mode;
 
     ctx->info.n_prims = s->n_prims;
     ctx->info.n_items = (uint32_t)groups.size();

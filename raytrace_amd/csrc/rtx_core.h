@@ -866,7 +866,8 @@ RTX_DEV V3 sample_direction(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
     uint32_t kind = kSampleCosine;
     Light E;
     E.a = E.b = E.c = E.d = E.e = 0.0f;
-    if (rng_nextf(&rng) < 0.5f) {
+    // no light shape: the material's own pdf alone, without the mixture's draw (wave-uniform)
+    if (sc.n_lights != 0u && rng_nextf(&rng) < 0.5f) {
         uint32_t index = 0;
         if (sc.light_is_list) {
             float r = rng_nextf(&rng);
@@ -1016,7 +1017,14 @@ struct PathState {
 RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitRec& rec, PathState& ps,
                    V3& L) {
     if (!hit) {  // Scene.cpp:131
-        L = vmul(ps.T, v3(sc.background));
+        V3 bg = v3(sc.background);
+        if (sc.background_mode == RTX_BACKGROUND_SKY) {  // Scene::backgroundSky, Scene.h:24-28
+            const V3 v = normalize(ps.d);
+            const float t = 0.5f * (v.y + 1.0f);
+            const V3 white = v3(1.0f, 1.0f, 1.0f);
+            bg = white + (v3(0.5f, 0.7f, 1.0f) - white) * t;  // lerp, vec_aos.h:92-95
+        }
+        L = vmul(ps.T, bg);
         return true;
     }
     const uint32_t mat_kind = rec_mat_kind(rec);
@@ -1036,10 +1044,10 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
 #if !RTX_DET
         {   // the same estimator with 1 / |dir| shared between the densities
             const float len2 = dot(dir, dir), inv_len = finvsqrt(len2);
-            const float pdf0 = light_pdf_fast(sc, rec.p, dir, len2, inv_len);
             const float cosine = dot(dir, rec.n) * inv_len;
             const float pdf1 = (cosine > 0.0f ? cosine : 0.0f) * (1.0f / kPi);  // = the scattering pdf
-            const float pdf_value = 0.5f * pdf0 + 0.5f * pdf1;
+            const float pdf_value =
+                sc.n_lights != 0u ? 0.5f * light_pdf_fast(sc, rec.p, dir, len2, inv_len) + 0.5f * pdf1 : pdf1;
             if (!(pdf_value > 0.0f)) return true;
             ps.T = vmul(albedo, ps.T) * (pdf1 * frcp(pdf_value));
             ps.o = rec.p;
@@ -1049,10 +1057,10 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
         }
 #endif
         // MixturePdf::value, MixturePdf.h:9-13
-        float pdf0 = light_pdf(sc, rec.p, dir);
         float cosine = dot(normalize(dir), rec.n);  // CosinePdf.cpp:7
         float pdf1 = cosine > 0.0f ? fdiv(cosine, kPi) : 0.0f;
-        float pdf_value = 0.5f * pdf0 + 0.5f * pdf1;
+        float pdf_value = pdf1;  // no light shape: srec.pdf alone
+        if (sc.n_lights != 0u) pdf_value = 0.5f * light_pdf(sc, rec.p, dir) + 0.5f * pdf1;
         if (!(pdf_value > 0.0f)) return true;  // Scene.cpp:117,122-124
         // Lambertian::scattering_pdf, Lambertian.cpp:23-25: std::max(cos, 0) / PI
         float c0 = cosine < 0.0f ? 0.0f : cosine;

@@ -165,6 +165,7 @@ struct SceneView {
     uint32_t light_is_list;
     float cam_origin[3], cam_ll[3], cam_u[3], cam_v[3];
     float background[3];
+    uint32_t background_mode;  // RTX_BACKGROUND_*
 };
 
 struct TraceArgs {

@@ -211,6 +211,7 @@ const RtxScene* FlatScene::view() {
     std::memcpy(s.cam_u, m_cam[2], sizeof s.cam_u);
     std::memcpy(s.cam_v, m_cam[3], sizeof s.cam_v);
     std::memcpy(s.background, m_background, sizeof s.background);
+    s.background_mode = m_background_sky ? RTX_BACKGROUND_SKY : RTX_BACKGROUND_CONSTANT;
     return &s;
 }
 
@@ -555,25 +556,36 @@ void Scene::build() {
     m_light.reset(lights);
 }
 
+Vector3 Scene::backgroundSky(const Vector3& d) const {
+    Vector3 v = normalize(d);
+    float t = 0.5f * (v.getY() + 1.0f);
+    return lerp(t, Vector3(1.0f), Vector3(0.5f, 0.7f, 1.0f));
+}
+
 bool Scene::flatten(FlatScene& out) const {
-    if (!m_camera || !m_world || !m_light) {
-        out.fail("scene needs a camera, a world and a light shape (Scene::color takes a mandatory light, Scene.cpp:103)");
+    if (!m_camera || !m_world) {
+        out.fail("scene needs a camera and a world");
         return false;
     }
     FlatScene::Cursor cur;
     m_world->flatten(out, cur);
-    if (m_light->is_list()) {
+    if (!m_light) {
+        // no light shape at all: diffuse bounces sample the material's own pdf only (an
+        // extension; the reference's color() dereferences its light unconditionally)
+        out.set_light_is_list(true);
+    } else if (m_light->is_list()) {
         out.set_light_is_list(true);
         static_cast<const ShapeList*>(m_light.get())->flatten_as_light_list(out);
+        if (out.light_kind.empty())
+            out.fail("the light list is empty (undefined behaviour in the reference, ShapeList.cpp:28-35)");
     } else {
         out.set_light_is_list(false);
         m_light->flatten_light(out);
     }
-    if (out.light_kind.empty())
-        out.fail("the light list is empty (undefined behaviour in the reference, ShapeList.cpp:28-35)");
     if (out.prim_kind.empty()) out.fail("the world has no primitives");
     out.set_camera(*m_camera);
     out.set_background(m_backColor);
+    out.set_background_sky(m_backgroundSky);
     return out.error().empty();
 }
 

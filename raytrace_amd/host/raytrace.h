@@ -58,6 +58,8 @@ private:
     float mX, mY, mZ;
 };
 inline Vector3 operator*(float s, const Vector3& v) { return v * s; }
+// vec_aos.h:92-95
+inline Vector3 lerp(float t, const Vector3& a, const Vector3& b) { return a + ((b - a) * t); }
 inline float dot(const Vector3& a, const Vector3& b) {
     float r = a.getX() * b.getX();
     r = r + a.getY() * b.getY();
@@ -120,6 +122,7 @@ public:
     uint32_t new_material(uint32_t kind, uint32_t tex, float param);
     void set_camera(const Camera& cam);
     void set_background(const Vector3& c);
+    void set_background_sky(bool sky) { m_background_sky = sky; }
     void set_light_is_list(bool v) { m_light_is_list = v; }
     const std::string& error() const { return m_error; }
     void fail(const std::string& e) { if (m_error.empty()) m_error = e; }
@@ -142,6 +145,7 @@ private:
     bool m_light_is_list = true;
     float m_cam[4][3];
     float m_background[3];
+    bool m_background_sky = false;
     std::map<const Material*, uint32_t> m_mat_ids;
     std::map<const Texture*, uint32_t> m_tex_ids;
     std::string m_error;
@@ -429,6 +433,10 @@ public:
     void setLight(Shape* light) { m_light.reset(light); }
     void setBackground(const Vector3& c) { m_backColor = c; }
     Vector3 background(const Vector3&) const { return m_backColor; }
+    // Scene.h:24-28: the vertical white-to-blue gradient; the reference defines it but its
+    // color() never calls it.  setBackgroundSky(true) makes misses return it.
+    Vector3 backgroundSky(const Vector3& d) const;
+    void setBackgroundSky(bool sky) { m_backgroundSky = sky; }
 
     // render options the reference fixes at compile time
     void setMaxDepth(int d) { m_maxDepth = d; }          // MAX_DEPTH, Scene.cpp:9
@@ -453,6 +461,7 @@ protected:
     std::unique_ptr<Shape> m_world;
     int m_samples;
     std::unique_ptr<Shape> m_light;
+    bool m_backgroundSky = false;
     int m_maxDepth = 50;
     uint64_t m_seed = 0;
     bool m_deterministic = false;

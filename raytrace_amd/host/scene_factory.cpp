@@ -34,6 +34,7 @@ struct NamedScene : public Scene {
         setWorld(parts.world);
         setLight(parts.light);
         setBackground(parts.background);
+        setBackgroundSky(parts.sky);
     }
     bool built() const { return m_built; }
 

@@ -5,7 +5,7 @@ oracle/Makefile, fed the counter-based stream of include/rtx_det.h).
 
 Run from the repository root in a container that holds /root/reference:
     make -C oracle && python tests/golden/make_golden.py [section ...]
-(sections: texture samples hits misc flops gt; default all; "samples:textured" and
+(sections: texture samples hits misc pieces flops gt; default all; "samples:textured" and
 "hits:textured" restrict a section to one scene).
 The reference has no fixtures of its own for this path, so these files are what pins
 the CPU restatement (and through it the GPU path) wherever the reference is absent.
@@ -33,8 +33,13 @@ SAMPLE_CASES = [  # scene, w, h, spp_begin, spp, seed
     ("random_field", 32, 18, 0, 4, 7),
     ("bvh_stress_500", 24, 14, 0, 2, 7),
     ("textured", 48, 27, 0, 8, 7),
+    ("sky_spheres", 48, 27, 0, 8, 7),  # no light shape + sky: from the CPU restatement (see RESTATEMENT_ONLY)
 ]
-HIT_SCENES = ("cornell", "cornell_extra", "random_field", "bvh_stress_500", "textured")
+# Scenes the reference's color() cannot render (it dereferences its light, Scene.cpp:113, and
+# never calls backgroundSky): their vectors come from oracle/restate.cpp, whose pieces for this
+# mode are pinned against the reference function by function (sky_and_cosine_pdf.npz).
+RESTATEMENT_ONLY = ("sky_spheres",)
+HIT_SCENES = ("cornell", "cornell_extra", "random_field", "bvh_stress_500", "textured")  # + sky_spheres needs no hits: same shapes
 TEXTURE = os.path.join(HERE, "texture_64x32.bmp")
 
 
@@ -74,7 +79,7 @@ def rays_for(name, n, rng):
 
 def main(argv):
     assert ref.available(), "build oracle/_ref first"
-    sections = argv or ["texture", "samples", "hits", "misc", "flops", "gt"]
+    sections = argv or ["texture", "samples", "hits", "misc", "pieces", "flops", "gt"]
 
     def want(section, scene=None):
         return section in sections or (scene is not None and f"{section}:{scene}" in sections)
@@ -87,12 +92,17 @@ def main(argv):
     for name, w, h, s0, spp, seed in SAMPLE_CASES:
         if not want("samples", name):
             continue
-        r = ref.RefScene(name, w, h).render(s0, spp, seed=seed, threads=8, per_sample=True)
+        if name in RESTATEMENT_ONLY:
+            r = restate.render(api.HostScene(name, w, h), w, h, s0, spp, seed=seed, threads=8, per_sample=True)
+            r["draws"] = 0
+        else:
+            r = ref.RefScene(name, w, h).render(s0, spp, seed=seed, threads=8, per_sample=True)
         key = f"samples_{name}_{w}x{h}_s{s0}+{spp}_seed{seed}"
         np.savez_compressed(os.path.join(HERE, key + ".npz"), samples=r["samples"], segments=r["segments"].astype(np.uint8)
                             if r["segments"].max() < 256 else r["segments"], sum=r["sum"], rays=np.uint64(r["rays"]),
                             draws=np.uint64(r["draws"]))
-        out[key] = dict(scene=name, w=w, h=h, spp_begin=s0, spp=spp, seed=seed, rays=int(r["rays"]))
+        out[key] = dict(scene=name, w=w, h=h, spp_begin=s0, spp=spp, seed=seed, rays=int(r["rays"]),
+                        source="restatement" if name in RESTATEMENT_ONLY else "reference")
         print(key, r["rays"])
 
     with open(index_path, "w") as f:
@@ -112,10 +122,25 @@ def main(argv):
 
     if want("misc"):
         misc(np.random.default_rng(2026))
+    if want("pieces"):
+        pieces(np.random.default_rng(2027))
     if want("flops"):
         flops_per_ray()
     if want("gt"):
         ground_truth()
+
+
+def pieces(rng):
+    """The two functions of the reference that the sky / no-light extension is made of."""
+    d = rng.normal(size=(4096, 3)).astype(np.float32)
+    d[:6] = [[0, 1, 0], [0, -1, 0], [1, 0, 0], [0, 0, -3], [1e-3, 2e-3, 1e-3], [5e3, -4e3, 1e3]]
+    n = rng.normal(size=(4096, 3)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True).astype(np.float32)
+    n[:4] = [[0, 1, 0], [1, 0, 0], [0.95, 0.3122499, 0], [-0.9, 0, 0.43588989]]  # around |w.x| = 0.9 (ONB.h:30)
+    dirs, vals = ref.cosine_pdf(n, seed=11)
+    np.savez_compressed(os.path.join(HERE, "sky_and_cosine_pdf.npz"), sky_dirs=d, sky=ref.background_sky(d),
+                        normals=n, seed=np.uint64(11), cos_dirs=dirs, cos_values=vals)
+    print("pieces", float(ref.background_sky(d).mean()), float(vals.mean()))
 
 
 def misc(rng):

@@ -157,3 +157,13 @@ def test_missing_texture_file_is_an_error(tmp_path, monkeypatch):
     monkeypatch.setenv("RTX_TEXTURE", str(tmp_path / "junk.bmp"))
     with pytest.raises(ValueError):
         api.HostScene("textured", 16, 9)
+
+
+def test_scene_without_light_and_with_sky_background():
+    """No light shape and Scene::backgroundSky (Scene.h:24-28): an extension of the flattened
+    scene, since the reference's color() requires a light and never calls the gradient."""
+    a = api.HostScene("sky_spheres", 32, 18).arrays()
+    assert a["light_kind"].size == 0 and int(a["light_is_list"][0]) == 1
+    assert int(a["background_mode"][0]) == api.RTX_BACKGROUND_SKY
+    assert int(api.HostScene("small", 32, 18).arrays()["background_mode"][0]) == api.RTX_BACKGROUND_CONSTANT
+    assert a["prim_kind"].size == 4 + 6  # four spheres and the six rects of the box

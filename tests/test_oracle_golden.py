@@ -72,6 +72,17 @@ def test_bvh_flop_count_is_far_below_the_scan():
     assert bvh["flops"] < 0.2 * lin["flops"]
 
 
+def test_restatement_sky_and_cosine_pdf_match_reference():
+    """Scene::backgroundSky and CosinePdf, the two reference functions the sky / no-light
+    extension consists of (the reference's color() itself can render neither)."""
+    g = util.load_golden("sky_and_cosine_pdf")
+    assert np.array_equal(restate.background_sky(g["sky_dirs"]), g["sky"])
+    dirs, vals = restate.cosine_pdf(g["normals"], seed=int(g["seed"]))
+    assert np.array_equal(dirs, g["cos_dirs"])
+    assert np.array_equal(vals, g["cos_values"])
+    assert (vals > 0).all()
+
+
 def test_restatement_image_write_matches_reference():
     g = util.load_golden("image_write")
     assert np.array_equal(restate.image_write(g["rgb"]), g["rgb8"])

@@ -289,13 +289,15 @@ def test_fast_mode_hits_agree_with_golden_up_to_rounding(gpu_ctx, name, accel):
     assert du.max() < 5e-3
 
 
-def test_fast_mode_textured_scene_converges(gpu_ctx):
-    """Image textures in fast mode: the estimator of the CPU tracer on the same scene (mean
-    squared error over 12 seeds against a CPU ground truth, scan and BVH)."""
+@pytest.mark.parametrize("name", ["textured", "sky_spheres"])
+def test_fast_mode_converges_on_widened_scenes(gpu_ctx, name):
+    """Image textures / sky background without a light shape in fast mode: the estimator of the
+    CPU tracer on the same scene (mean squared error over 12 seeds against a CPU ground truth,
+    scan and BVH)."""
     from oracle import restate
 
     w, h, spp, seeds = 96, 54, 32, 12
-    scene = api.HostScene("textured", w, h)
+    scene = api.HostScene(name, w, h)
     gt = np.clip(restate.render(scene, w, h, 1000, 1024, seed=5, threads=8)["sum"] / 1024, 0, 1)
 
     def mse(img):
