@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 3u
+#define RTX_ABI_VERSION 4u
 
 typedef enum RtxStatus {
     RTX_OK = 0,
@@ -38,9 +38,23 @@ typedef enum RtxStatus {
 
 /* Primitive kinds (Rect::AxisType, Rect.h:7-11, plus Sphere). */
 enum { RTX_PRIM_RECT_XY = 0, RTX_PRIM_RECT_XZ = 1, RTX_PRIM_RECT_YZ = 2, RTX_PRIM_SPHERE = 3 };
-/* Light-list entry kinds; OTHER = any shape that keeps Shape's default
- * pdf_value()/random() (Shape.h:8-9: 0 and (1,0,0)). */
-enum { RTX_LIGHT_RECT_XY = 0, RTX_LIGHT_RECT_XZ = 1, RTX_LIGHT_RECT_YZ = 2, RTX_LIGHT_SPHERE = 3, RTX_LIGHT_OTHER = 4 };
+/* Light entry kinds; OTHER = any shape that keeps Shape's default pdf_value()/random()
+ * (Shape.h:8-9: 0 and (1,0,0)); LIST = a ShapeList nested inside the light shape
+ * (ShapeList.cpp:19-35 recurse into it). */
+enum {
+    RTX_LIGHT_RECT_XY = 0, RTX_LIGHT_RECT_XZ = 1, RTX_LIGHT_RECT_YZ = 2, RTX_LIGHT_SPHERE = 3, RTX_LIGHT_OTHER = 4,
+    RTX_LIGHT_LIST = 5
+};
+/* Which shapes can be sampled as lights.
+ *   REFERENCE  exactly the reference: only XZ rects (Rect.cpp:37,51) and spheres have a density
+ *              and a sampler; XY / YZ rects and every FlipNormals / Translate / Rotate / Box
+ *              wrapper keep Shape's defaults, 0 and (1,0,0) (Shape.h:8-9).
+ *   GENERAL    an extension with no counterpart in the reference: rects of all three axes are
+ *              sampled by area like the XZ one, and a leaf entry may sit under a transform
+ *              chain: pdf_value(o, v) and random(o) take o (and v) into the leaf's frame the way
+ *              Translate::hit / Rotate::hit take a ray (Translate.cpp:7, Rotate.cpp:7-9), and
+ *              random()'s direction is rotated back out (Rotate.cpp:13). */
+enum { RTX_LIGHTS_REFERENCE = 0, RTX_LIGHTS_GENERAL = 1 };
 /* Transform steps (Translate.h:7, Rotate.h:7). */
 enum { RTX_STEP_TRANSLATE = 0, RTX_STEP_ROTATE = 1 };
 /* Material kinds (Lambertian.h, Metal.h, Dielectric.h, DiffuseLight.h). */
@@ -114,10 +128,10 @@ typedef struct RtxScene {
      * reference's color() always takes a light) means there is none: a diffuse bounce is then
      * sampled from the material's own pdf alone, srec.pdf of Lambertian.cpp:19, with no
      * mixture and no extra draw. */
-    uint32_t n_lights;
+    uint32_t n_lights;             /* entries of the top-level list, or 1 for a bare shape */
     uint32_t light_is_list;        /* 1: a ShapeList (one extra draw picks the entry,
                                       ShapeList.cpp:28-35); 0: a single bare shape */
-    const uint32_t* light_kind;    /* RTX_LIGHT_* */
+    const uint32_t* light_kind;    /* RTX_LIGHT_*; n_light_entries of each light_* array */
     const float* light_a;          /* same meaning as prim_a..prim_e */
     const float* light_b;
     const float* light_c;
@@ -132,6 +146,19 @@ typedef struct RtxScene {
 
     float background[3];           /* Scene::background (Scene.h:20-22) */
     uint32_t background_mode;      /* RTX_BACKGROUND_*; SKY ignores background[] */
+
+    /* Light trees.  Entries [0, n_lights) of the light_* arrays are the top-level list (or the
+     * one bare shape).  A ShapeList nested in it is an entry of kind RTX_LIGHT_LIST; its
+     * children are the entries [light_first[l], light_first[l] + light_count[l]), which lie
+     * behind the top-level ones and may be lists again.  A nested list draws one more number to
+     * pick a child and weighs its children's densities by 1 / count (ShapeList.cpp:19-35). */
+    uint32_t n_light_entries;      /* length of the light_* arrays; 0 means n_lights */
+    uint32_t light_sampling;       /* RTX_LIGHTS_* */
+    const uint32_t* light_first;   /* LIST entries only; may be NULL when there is none */
+    const uint32_t* light_count;   /* LIST entries only, >= 1 (the reference indexes an empty
+                                      list out of bounds, ShapeList.cpp:28-35) */
+    const uint32_t* light_chain;   /* RTX_LIGHTS_GENERAL: index into chain_begin of each leaf
+                                      entry's transform chain; NULL = none has one */
 } RtxScene;
 
 typedef struct RtxParams {

@@ -100,7 +100,7 @@ void* ref_scene_create(const char* name, int w, int h) {
     } else {
         SceneParts parts;
         if (!make_scene(name, w, h, parts)) return nullptr;
-        if (parts.sky || !parts.light) {  // the reference's color() cannot render these
+        if (parts.sky || !parts.light || parts.general_lights) {  // the reference's color() cannot render these
             delete parts.camera;
             delete parts.world;
             delete parts.light;

@@ -500,17 +500,55 @@ public:
     // ONB::local, ONB.h:24-26
     Vec<F> basis_local(const Basis& b, const Vec<F>& a) const { return b.u * a.x + b.v * a.y + b.w * a.z; }
 
-    // Shape::pdf_value of one light entry: Rect.cpp:36-48, Sphere.cpp:38-50, Shape.h:8
-    F light_entry_pdf(uint32_t l, const Vec<F>& o, const Vec<F>& v) const {
+    // A light entry's frame (general light sampling only; the reference's Translate / Rotate keep
+    // Shape's default pdf_value / random, Shape.h:8-9): the query enters it as a ray enters
+    // Translate::hit / Rotate::hit (Translate.cpp:7, Rotate.cpp:7-9).
+    bool general_lights() const { return sc.light_sampling == RTX_LIGHTS_GENERAL; }
+    void light_chain_of(uint32_t l, uint32_t& sb, uint32_t& se) const {
+        const uint32_t c = general_lights() && sc.light_chain ? sc.light_chain[l] : 0u;
+        sb = sc.chain_begin[c];
+        se = sc.chain_begin[c + 1];
+    }
+    void enter_light_frame(uint32_t l, Vec<F>& o, Vec<F>* v) const {
+        uint32_t sb, se;
+        light_chain_of(l, sb, se);
+        for (uint32_t s = sb; s < se; ++s) {
+            if (sc.step_kind[s] == RTX_STEP_TRANSLATE) {
+                o = o - Vec<F>(sc.step_x[s], sc.step_y[s], sc.step_z[s]);
+            } else {
+                F qx = -sc.step_x[s], qy = -sc.step_y[s], qz = -sc.step_z[s], qw = sc.step_w[s];  // conj
+                o = rotate(qx, qy, qz, qw, o);
+                if (v) *v = rotate(qx, qy, qz, qw, *v);
+            }
+        }
+    }
+    bool samples_as_rect(uint32_t kind) const {
+        return kind == RTX_LIGHT_RECT_XZ || (general_lights() && kind <= RTX_LIGHT_RECT_YZ);
+    }
+
+    // Shape::pdf_value of one light entry: ShapeList.cpp:19-26 (a nested list), Rect.cpp:36-48 (the
+    // XZ rect; with general light sampling the same for the rect's own axis), Sphere.cpp:38-50, Shape.h:8
+    F light_entry_pdf(uint32_t l, const Vec<F>& o_in, const Vec<F>& v_in) const {
         const uint32_t kind = sc.light_kind[l];
-        if (kind == RTX_LIGHT_RECT_XZ) {
+        if (kind == RTX_LIGHT_LIST) {
+            const uint32_t first = sc.light_first[l], n = sc.light_count[l];
+            F weight = F(1.0f) / F((float)n);
+            F sum = 0.0f;
+            for (uint32_t k = 0; k < n; ++k) sum = sum + weight * light_entry_pdf(first + k, o_in, v_in);
+            return sum;
+        }
+        Vec<F> o = o_in, v = v_in;
+        enter_light_frame(l, o, &v);
+        if (samples_as_rect(kind)) {
             F t;
-            if (!rect_hit(RTX_PRIM_RECT_XZ, sc.light_a[l], sc.light_b[l], sc.light_c[l], sc.light_d[l], sc.light_e[l], o, v,
+            if (!rect_hit(kind, sc.light_a[l], sc.light_b[l], sc.light_c[l], sc.light_d[l], sc.light_e[l], o, v,
                           F(0.001f), F(FLT_MAX), t))
                 return F(0.0f);
             F area = (F(sc.light_b[l]) - F(sc.light_a[l])) * (F(sc.light_d[l]) - F(sc.light_c[l]));
             F distance_squared = (t * t) * length_sqr(v);
-            F cosine = f_abs(dot(v, Vec<F>(0.0f, 1.0f, 0.0f))) / length(v);
+            const Vec<F> normal(kind == RTX_LIGHT_RECT_YZ ? 1.0f : 0.0f, kind == RTX_LIGHT_RECT_XZ ? 1.0f : 0.0f,
+                                kind == RTX_LIGHT_RECT_XY ? 1.0f : 0.0f);
+            F cosine = f_abs(dot(v, normal)) / length(v);
             return distance_squared / (cosine * area);
         }
         if (kind == RTX_LIGHT_SPHERE) {
@@ -537,15 +575,27 @@ public:
         return sum;
     }
 
-    // Shape::random of one light entry: Rect.cpp:50-68, Sphere.cpp:52-58 (+ Util.h:96-107), Shape.h:9
-    Vec<F> light_entry_random(uint32_t l, const Vec<F>& o) {
+    // Shape::random of one light entry: ShapeList.cpp:28-35 (a nested list draws again), Rect.cpp:50-68,
+    // Sphere.cpp:52-58 (+ Util.h:96-107), Shape.h:9
+    Vec<F> light_entry_random(uint32_t l, const Vec<F>& o_in) {
         const uint32_t kind = sc.light_kind[l];
-        if (kind == RTX_LIGHT_RECT_XZ) {
+        if (kind == RTX_LIGHT_LIST) {
+            size_t n = sc.light_count[l];
+            size_t index = size_t(raw(draw()) * (float)n);
+            if (n > 0 && index >= n) index = n - 1;
+            return light_entry_random(sc.light_first[l] + (uint32_t)index, o_in);
+        }
+        if (!samples_as_rect(kind) && kind != RTX_LIGHT_SPHERE) return Vec<F>(1.0f, 0.0f, 0.0f);
+        Vec<F> o = o_in;
+        enter_light_frame(l, o, nullptr);
+        Vec<F> dir;
+        if (samples_as_rect(kind)) {
             F x = F(sc.light_a[l]) + draw() * (F(sc.light_b[l]) - F(sc.light_a[l]));
             F y = F(sc.light_c[l]) + draw() * (F(sc.light_d[l]) - F(sc.light_c[l]));
-            return Vec<F>(x, sc.light_e[l], y) - o;
-        }
-        if (kind == RTX_LIGHT_SPHERE) {
+            const F k = sc.light_e[l];
+            const Vec<F> point = kind == RTX_LIGHT_RECT_XY ? Vec<F>(x, y, k) : (kind == RTX_LIGHT_RECT_XZ ? Vec<F>(x, k, y) : Vec<F>(k, x, y));
+            dir = point - o;
+        } else {
             Vec<F> direction = Vec<F>(sc.light_a[l], sc.light_b[l], sc.light_c[l]) - o;
             F distance_squared = length_sqr(direction);
             Basis uvw = basis_from_w(direction);
@@ -560,9 +610,18 @@ public:
             F phi = F(kPI2) * r1;
             F sn, cs;
             f_sincos(phi, sn, cs);
-            return basis_local(uvw, Vec<F>(cs * sqrtz, sn * sqrtz, z));
+            dir = basis_local(uvw, Vec<F>(cs * sqrtz, sn * sqrtz, z));
         }
-        return Vec<F>(1.0f, 0.0f, 0.0f);
+        // out of the entry's frame as a normal leaves Rotate::hit (Rotate.cpp:13), innermost wrapper first
+        uint32_t sb, se;
+        light_chain_of(l, sb, se);
+        for (uint32_t s = se; s > sb; --s) {
+            const uint32_t q = s - 1;
+            if (sc.step_kind[q] != RTX_STEP_ROTATE) continue;
+            F qx = sc.step_x[q], qy = sc.step_y[q], qz = sc.step_z[q], qw = sc.step_w[q];
+            dir = rotate(qx, qy, qz, qw, dir);
+        }
+        return dir;
     }
 
     // ShapePdf::generate (ShapePdf.h:15-17) -> ShapeList::random (ShapeList.cpp:28-35)

@@ -15,13 +15,15 @@ import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
-RTX_ABI_VERSION = 3
+RTX_ABI_VERSION = 4
 RTX_ACCEL_AUTO, RTX_ACCEL_LINEAR, RTX_ACCEL_BVH = 0, 1, 2
 RTX_MODE_FAST, RTX_MODE_DETERMINISTIC = 0, 1
 RTX_PRIM_RECT_XY, RTX_PRIM_RECT_XZ, RTX_PRIM_RECT_YZ, RTX_PRIM_SPHERE = 0, 1, 2, 3
 RTX_MAT_LAMBERTIAN, RTX_MAT_METAL, RTX_MAT_DIELECTRIC, RTX_MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
 RTX_TEX_COLOR, RTX_TEX_CHECKER, RTX_TEX_IMAGE = 0, 1, 2
 RTX_BACKGROUND_CONSTANT, RTX_BACKGROUND_SKY = 0, 1
+RTX_LIGHT_RECT_XY, RTX_LIGHT_RECT_XZ, RTX_LIGHT_RECT_YZ, RTX_LIGHT_SPHERE, RTX_LIGHT_OTHER, RTX_LIGHT_LIST = range(6)
+RTX_LIGHTS_REFERENCE, RTX_LIGHTS_GENERAL = 0, 1
 RTX_OK = 0
 RTX_ERR_INVALID_ARGUMENT, RTX_ERR_NO_DEVICE, RTX_ERR_HIP = -1, -2, -3
 RTX_ERR_NO_SCENE, RTX_ERR_UNSUPPORTED, RTX_ERR_TOO_LARGE = -4, -5, -6
@@ -59,6 +61,9 @@ class RtxScene(C.Structure):
         ("cam_u", C.c_float * 3), ("cam_v", C.c_float * 3),
         ("background", C.c_float * 3),
         ("background_mode", C.c_uint32),
+        ("n_light_entries", C.c_uint32),
+        ("light_sampling", C.c_uint32),
+        ("light_first", _u32p), ("light_count", _u32p), ("light_chain", _u32p),
     ]
 
 
@@ -231,23 +236,27 @@ class HostScene:
         """Copy of every array of the flattened scene, for inspection and fixtures."""
         s = self.view
         out = {}
+        n_le = s.n_light_entries or s.n_lights  # all light entries, nested lists included
         for name, n in (("prim_kind", s.n_prims), ("prim_flip", s.n_prims), ("prim_material", s.n_prims),
                         ("prim_chain", s.n_prims), ("chain_begin", s.n_chains + 1), ("step_kind", s.n_steps),
                         ("mat_kind", s.n_materials), ("mat_texture", s.n_materials),
                         ("tex_kind", s.n_textures), ("tex_odd", s.n_textures), ("tex_even", s.n_textures),
                         ("tex_offset", s.n_textures),
-                        ("light_kind", s.n_lights)):
-            out[name] = _as_np(getattr(s, name), n, np.uint32)
+                        ("light_kind", n_le), ("light_first", n_le), ("light_count", n_le),
+                        ("light_chain", n_le)):
+            out[name] = _as_np(getattr(s, name), n, np.uint32) if getattr(s, name) else np.zeros(n, np.uint32)
         for name, n in (("prim_a", s.n_prims), ("prim_b", s.n_prims), ("prim_c", s.n_prims),
                         ("prim_d", s.n_prims), ("prim_e", s.n_prims), ("step_x", s.n_steps),
                         ("step_y", s.n_steps), ("step_z", s.n_steps), ("step_w", s.n_steps),
                         ("mat_param", s.n_materials), ("tex_r", s.n_textures), ("tex_g", s.n_textures),
-                        ("tex_b", s.n_textures), ("light_a", s.n_lights), ("light_b", s.n_lights),
-                        ("light_c", s.n_lights), ("light_d", s.n_lights), ("light_e", s.n_lights)):
+                        ("tex_b", s.n_textures), ("light_a", n_le), ("light_b", n_le),
+                        ("light_c", n_le), ("light_d", n_le), ("light_e", n_le)):
             out[name] = _as_np(getattr(s, name), n, np.float32)
         for name in ("cam_origin", "cam_ll", "cam_u", "cam_v", "background"):
             out[name] = np.array(list(getattr(s, name)), np.float32)
         out["light_is_list"] = np.array([s.light_is_list], np.uint32)
+        out["n_lights"] = np.array([s.n_lights], np.uint32)
+        out["light_sampling"] = np.array([s.light_sampling], np.uint32)
         out["background_mode"] = np.array([s.background_mode], np.uint32)
         out["texels"] = _as_np(s.texels, int(s.n_texel_bytes), np.uint8)
         return out

@@ -71,6 +71,7 @@ struct RtxContext {
     DeviceArray<rtxd::Texture> textures;
     DeviceArray<uint8_t> texels;
     DeviceArray<rtxd::Light> lights;
+    DeviceArray<rtxd::LightNode> light_nodes;
     DeviceArray<rtxd::ScanGroup> scan_groups;
     DeviceArray<rtxd::ScanRec> scan_recs;
     DeviceArray<rtxd::ScanHit> scan_info;
@@ -142,8 +143,22 @@ int check_scene(const RtxScene* s) {
             (s->tex_odd[t] >= s->n_textures || s->tex_even[t] >= s->n_textures))
             return fail(RTX_ERR_INVALID_ARGUMENT, "checker sub-texture out of range");
     }
-    for (uint32_t l = 0; l < s->n_lights; ++l)
-        if (s->light_kind[l] > RTX_LIGHT_OTHER) return fail(RTX_ERR_INVALID_ARGUMENT, "bad light_kind");
+    if (s->light_sampling > RTX_LIGHTS_GENERAL) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown light_sampling");
+    const uint32_t n_entries = s->n_light_entries ? s->n_light_entries : s->n_lights;
+    if (n_entries < s->n_lights) return fail(RTX_ERR_INVALID_ARGUMENT, "n_light_entries < n_lights");
+    for (uint32_t l = 0; l < n_entries; ++l) {
+        if (s->light_kind[l] > RTX_LIGHT_LIST) return fail(RTX_ERR_INVALID_ARGUMENT, "bad light_kind");
+        if (s->light_kind[l] == RTX_LIGHT_LIST) {
+            if (!s->light_first || !s->light_count)
+                return fail(RTX_ERR_INVALID_ARGUMENT, "a nested light list needs light_first / light_count");
+            const uint32_t first = s->light_first[l], count = s->light_count[l];
+            // children lie behind their list and behind the top-level entries: no cycles, no sharing
+            if (count == 0 || first <= l || first < s->n_lights || first > n_entries || count > n_entries - first)
+                return fail(RTX_ERR_INVALID_ARGUMENT, "nested light list: bad child range");
+        } else if (s->light_sampling == RTX_LIGHTS_GENERAL && s->light_chain && s->light_chain[l] >= s->n_chains) {
+            return fail(RTX_ERR_INVALID_ARGUMENT, "light_chain out of range");
+        }
+    }
     if (!s->light_is_list && s->n_lights != 1)
         return fail(RTX_ERR_INVALID_ARGUMENT,
                     "a bare (non-list) light shape must have exactly one entry (no light at all: n_lights = 0 "
@@ -472,13 +487,32 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
         T.offset = s->tex_offset[t];
         T.pad = 0;
     }
-    std::vector<rtxd::Light> lights(s->n_lights);
-    for (uint32_t l = 0; l < s->n_lights; ++l) {
+    const uint32_t n_light_entries = s->n_light_entries ? s->n_light_entries : s->n_lights;
+    const bool general_lights = s->light_sampling == RTX_LIGHTS_GENERAL;
+    std::vector<rtxd::Light> lights(n_light_entries);
+    std::vector<rtxd::LightNode> light_nodes(n_light_entries);
+    bool light_tree = false;
+    for (uint32_t l = 0; l < n_light_entries; ++l) {
         rtxd::Light& E = lights[l];
         E.a = s->light_a[l]; E.b = s->light_b[l]; E.c = s->light_c[l]; E.d = s->light_d[l]; E.e = s->light_e[l];
         E.kind = s->light_kind[l];
         E.inv_area = E.kind <= RTX_LIGHT_RECT_YZ ? 1.0f / ((E.b - E.a) * (E.d - E.c)) : 0.0f;
         E.pad = 0;
+        rtxd::LightNode& N = light_nodes[l];  // value-initialised; a nested entry's weight is already set by its list
+        // ShapeList::pdf_value weighs each entry by 1.0f / size (ShapeList.cpp:20); nested lists multiply
+        if (l < s->n_lights) N.weight = s->light_is_list ? 1.0f / (float)s->n_lights : 1.0f;
+        if (E.kind == RTX_LIGHT_LIST) {
+            light_tree = true;
+            N.first = s->light_first[l];
+            N.count = s->light_count[l];
+            const float w = 1.0f / (float)N.count;
+            for (uint32_t k = 0; k < N.count; ++k) light_nodes[N.first + k].weight = N.weight * w;  // children lie behind l
+        } else if (general_lights) {
+            const uint32_t c = s->light_chain ? s->light_chain[l] : 0u;
+            N.step_begin = s->chain_begin[c];
+            N.step_end = s->chain_begin[c + 1];
+            if (N.step_end > N.step_begin || E.kind == RTX_LIGHT_RECT_XY || E.kind == RTX_LIGHT_RECT_YZ) light_tree = true;
+        }
     }
     // one record per primitive with all the integrator needs after a hit
     std::vector<rtxd::PrimInfo> info(s->n_prims);
@@ -530,6 +564,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     RTX_HIP(ctx->textures.upload(texs));
     RTX_HIP(ctx->texels.upload(std::vector<uint8_t>(s->texels, s->texels + s->n_texel_bytes)));
     RTX_HIP(ctx->lights.upload(lights));
+    RTX_HIP(ctx->light_nodes.upload(light_nodes));
     RTX_HIP(ctx->scan_groups.upload(scan_groups));
     RTX_HIP(ctx->scan_recs.upload(scan_recs));
     RTX_HIP(ctx->scan_info.upload(scan_info));
@@ -564,6 +599,9 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     v.n_lights = s->n_lights;
     v.n_bvh_nodes = (uint32_t)nodes.size();
     v.light_is_list = s->light_is_list ? 1u : 0u;
+    v.light_nodes = ctx->light_nodes.ptr;
+    v.n_light_entries = n_light_entries;
+    v.light_flags = (general_lights ? rtxd::kLightsGeneral : 0u) | (light_tree ? rtxd::kLightsTree : 0u);
     std::memcpy(v.cam_origin, s->cam_origin, sizeof v.cam_origin);
     std::memcpy(v.cam_ll, s->cam_ll, sizeof v.cam_ll);
     std::memcpy(v.cam_u, s->cam_u, sizeof v.cam_u);

@@ -979,6 +979,125 @@ RTX_DEV float light_pdf_fast(const SceneView& sc, V3 o, V3 v, float len2, float 
 }
 #endif
 
+
+// ---------------------------------------------------------------------------
+// light trees and general light shapes (kernels instantiated with kLightTree)
+// ---------------------------------------------------------------------------
+// The light shape as a tree: ShapeList entries may be ShapeLists again (ShapeList.cpp:19-35
+// recurse: random() draws one more number per level, pdf_value() weighs each level by 1 / n),
+// and - with general light sampling, which the reference does not have - a leaf may be a rect of
+// any axis and may sit under Translate / Rotate wrappers.  A wrapped leaf answers in its own
+// frame: the query point (and direction) enter it as a ray enters Translate::hit / Rotate::hit
+// (Translate.cpp:7, Rotate.cpp:7-9) and a sampled direction leaves it as a normal does
+// (Rotate.cpp:13; a translation does not change a direction).
+
+// Shape::pdf_value of a leaf for a query already in the leaf's frame: Rect.cpp:36-48 (for the
+// rect's own axis instead of XZ only when `general`), Sphere.cpp:38-50, Shape.h:8.
+RTX_DEV float light_pdf_leaf(const Light& E, V3 o, V3 v, bool general) {
+    const uint32_t kind = E.kind;
+    if (kind == RTX_LIGHT_RECT_XZ || (general && kind <= RTX_LIGHT_RECT_YZ)) {
+        float t;
+        const RayAux aux = make_aux(o, v);
+        if (!rect_test(kind, E.a, E.b, E.c, E.d, E.e, o, v, aux, kTMin, kFltMax, t)) return 0.0f;
+        const float vn = kind == RTX_LIGHT_RECT_XY ? v.z : (kind == RTX_LIGHT_RECT_XZ ? v.y : v.x);
+        float area = (E.b - E.a) * (E.d - E.c);
+        float distance_squared = (t * t) * length_sqr(v);
+        float cosine = fdiv(__builtin_fabsf(vn), length(v));
+        return fdiv(distance_squared, cosine * area);
+    }
+    if (kind == RTX_LIGHT_SPHERE) {
+        float t;
+        if (!sphere_test(E.a, E.b, E.c, E.d, o, v, kTMin, kFltMax, t)) return 0.0f;
+        float dd = length_sqr(v3(E.a, E.b, E.c) - o);
+        float r2r = E.d * E.d;
+        float rr = dd < r2r ? dd : r2r;
+        float cos_theta_max = fsqrt(1.0f - rr * frcp(dd));
+        float solid_angle = kPi2 * (1.0f - cos_theta_max);
+        return frcp(solid_angle);
+    }
+    return 0.0f;
+}
+
+// ShapePdf::value over the whole tree: the sum over the leaves of (product of the 1 / n above
+// the leaf) * its density.  The reference nests the sums (ShapeList.cpp:19-26); for a flat list
+// this is the same sum in the same order, for nested lists it differs by rounding only.
+RTX_DEV float light_pdf_tree(const SceneView& sc, V3 o, V3 v) {
+    const bool general = (sc.light_flags & kLightsGeneral) != 0u;
+    float sum = 0.0f;
+    for (uint32_t e = 0; e < sc.n_light_entries; ++e) {
+        const Light E = load_uniform(sc.lights, e);
+        if (E.kind >= RTX_LIGHT_OTHER) continue;  // no density of its own (Shape.h:8) / a list
+        const LightNode N = load_uniform(sc.light_nodes, e);
+        V3 ol = o, vl = v;
+        enter_group<true>(sc, N.step_begin, N.step_end, ol, vl);
+        sum = sum + N.weight * light_pdf_leaf(E, ol, vl, general);
+    }
+    return sum;
+}
+
+// MixturePdf::generate (MixturePdf.h:15-22) with the light shape as a tree.
+RTX_DEV V3 sample_direction_tree(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
+    if (sc.n_lights != 0u && rng_nextf(&rng) < 0.5f) {
+        uint32_t index = 0;
+        if (sc.light_is_list) {  // ShapeList::random, ShapeList.cpp:28-35
+            float r = rng_nextf(&rng);
+            index = (uint32_t)(r * (float)sc.n_lights);
+            if (index >= sc.n_lights) index = sc.n_lights - 1;
+        }
+        Light E = sc.lights[index];  // per lane
+        for (int level = 0; level < 16 && E.kind == RTX_LIGHT_LIST; ++level) {  // a nested list picks again
+            const LightNode L = sc.light_nodes[index];
+            float r = rng_nextf(&rng);
+            uint32_t k = (uint32_t)(r * (float)L.count);
+            if (k >= L.count) k = L.count - 1;
+            index = L.first + k;
+            E = sc.lights[index];
+        }
+        const bool general = (sc.light_flags & kLightsGeneral) != 0u;
+        const bool is_rect = E.kind == RTX_LIGHT_RECT_XZ || (general && E.kind <= RTX_LIGHT_RECT_YZ);
+        if (!is_rect && E.kind != RTX_LIGHT_SPHERE) return v3(1.0f, 0.0f, 0.0f);  // Shape.h:9
+        const LightNode N = sc.light_nodes[index];
+        V3 ol = o, unused = v3(0.0f, 0.0f, 0.0f);
+        enter_group<false>(sc, N.step_begin, N.step_end, ol, unused);
+        V3 dir;
+        if (is_rect) {  // Rect.cpp:50-68, for the rect's own axis
+            float x = E.a + rng_nextf(&rng) * (E.b - E.a);
+            float y = E.c + rng_nextf(&rng) * (E.d - E.c);
+            const V3 point = E.kind == RTX_LIGHT_RECT_XY ? v3(x, y, E.e)
+                                                         : (E.kind == RTX_LIGHT_RECT_XZ ? v3(x, E.e, y) : v3(E.e, x, y));
+            dir = point - ol;
+        } else {  // Sphere.cpp:52-58 with random_to_sphere, Util.h:96-107
+            const V3 axis = v3(E.a, E.b, E.c) - ol;
+            float dd = length_sqr(axis);
+            const Onb uvw = onb_from_w(axis);
+            const float r1 = rng_nextf(&rng);
+            const float r2 = rng_nextf(&rng);
+            float r2r = E.d * E.d;
+            float rr = dd < r2r ? dd : r2r;
+            float cos_theta_max = fsqrt(1.0f - rr * frcp(dd));
+            float z = 1.0f - r2 * (1.0f - cos_theta_max);
+            float radial = fsqrt(1.0f - z * z);
+            float sn, cs;
+            sincos_2pi(r1, sn, cs);
+            dir = onb_local(uvw, v3(cs * radial, sn * radial, z));
+        }
+        for (uint32_t s = N.step_end; s > N.step_begin; --s) {  // out of the leaf's frame, innermost wrapper first
+            const Step S = sc.steps[s - 1];
+            if (S.kind == RTX_STEP_ROTATE) dir = qrotate(S.x, S.y, S.z, S.w, dir);
+        }
+        return dir;
+    }
+    // CosinePdf::generate (CosinePdf.cpp:16-20) with random_cosine_direction (Util.h:86-94)
+    const Onb uvw = onb_from_w(n);
+    const float r1 = rng_nextf(&rng);
+    const float r2 = rng_nextf(&rng);
+    float z = fsqrt(1.0f - r2);
+    float radial = fsqrt(r2);
+    float sn, cs;
+    sincos_2pi(r1, sn, cs);
+    return onb_local(uvw, v3(cs * radial, sn * radial, z));
+}
+
 // ---------------------------------------------------------------------------
 // reflect / refract / schlick, Util.h:56-76
 // ---------------------------------------------------------------------------
@@ -1014,6 +1133,7 @@ struct PathState {
     RtxRng rng;
 };
 
+template <bool kLightTree>
 RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitRec& rec, PathState& ps,
                    V3& L) {
     if (!hit) {  // Scene.cpp:131
@@ -1040,9 +1160,10 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
 
     if (mat_kind == RTX_MAT_LAMBERTIAN) {
         V3 albedo = surface_color(sc, rec);  // Lambertian.cpp:17
-        const V3 dir = sample_direction(sc, rec.p, rec.n, ps.rng);
+        const V3 dir = kLightTree ? sample_direction_tree(sc, rec.p, rec.n, ps.rng)
+                                  : sample_direction(sc, rec.p, rec.n, ps.rng);
 #if !RTX_DET
-        {   // the same estimator with 1 / |dir| shared between the densities
+        if (!kLightTree) {  // the same estimator with 1 / |dir| shared between the densities
             const float len2 = dot(dir, dir), inv_len = finvsqrt(len2);
             const float cosine = dot(dir, rec.n) * inv_len;
             const float pdf1 = (cosine > 0.0f ? cosine : 0.0f) * (1.0f / kPi);  // = the scattering pdf
@@ -1060,7 +1181,8 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
         float cosine = dot(normalize(dir), rec.n);  // CosinePdf.cpp:7
         float pdf1 = cosine > 0.0f ? fdiv(cosine, kPi) : 0.0f;
         float pdf_value = pdf1;  // no light shape: srec.pdf alone
-        if (sc.n_lights != 0u) pdf_value = 0.5f * light_pdf(sc, rec.p, dir) + 0.5f * pdf1;
+        if (sc.n_lights != 0u)
+            pdf_value = 0.5f * (kLightTree ? light_pdf_tree(sc, rec.p, dir) : light_pdf(sc, rec.p, dir)) + 0.5f * pdf1;
         if (!(pdf_value > 0.0f)) return true;  // Scene.cpp:117,122-124
         // Lambertian::scattering_pdf, Lambertian.cpp:23-25: std::max(cos, 0) / PI
         float c0 = cosine < 0.0f ? 0.0f : cosine;
@@ -1142,7 +1264,7 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
 // pixel slot l to HBM once, at the end.  Only this wave touches its slice of LDS, and the wave
 // executes in lockstep, so the order of the adds - and with it every bit of the result -
 // is reproducible from run to run.
-template <bool kBvh, bool kSamples>
+template <bool kBvh, bool kSamples, bool kLightTree>
 __global__ void __launch_bounds__(RTX_BLOCK, kBvh ? RTX_TRACE_WAVES_BVH : RTX_TRACE_WAVES) trace_kernel(const TraceArgs a) {
     __shared__ float s_acc[RTX_BLOCK / 64][3][64];
 #ifdef RTX_PROBE_LDS_BYTES  // occupancy experiments: LDS ballast that caps the resident blocks per CU
@@ -1212,7 +1334,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, kBvh ? RTX_TRACE_WAVES_BVH : RTX_TR
             bool hit = scene_hit<kBvh>(sc, ps.o, ps.d, kTMin, kFltMax, rec);
             ++segs;
             V3 L;
-            if (shade(sc, a.max_depth, hit, rec, ps, L)) {
+            if (shade<kLightTree>(sc, a.max_depth, hit, rec, ps, L)) {
                 const uint32_t slot = item & pix_mask;
                 atomicAdd(&s_acc[wave][0][slot], L.x);  // Scene.cpp:148
                 atomicAdd(&s_acc[wave][1][slot], L.y);
@@ -1277,7 +1399,7 @@ constexpr uint32_t kShadeBatch = RTX_SHADE_BATCH;
 #endif
 constexpr uint32_t kLeafBatch = RTX_LEAF_BATCH;
 
-template <bool kUnused>
+template <bool kLightTree>
 __global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES_BVH) trace_bvh_kernel(const TraceArgs a) {
     __shared__ float s_acc[RTX_BLOCK / 64][3][64];
     __shared__ uint32_t s_stack[kBvhStack][RTX_BLOCK];
@@ -1327,7 +1449,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES_BVH) trace_bvh_kern
                 if (hit) finish_scan_hit<true>(sc, best, closest, ps.o, ps.d, false, rec);
                 ++segs;
                 V3 L;
-                if (shade(sc, a.max_depth, hit, rec, ps, L)) {
+                if (shade<kLightTree>(sc, a.max_depth, hit, rec, ps, L)) {
                     const uint32_t slot = item & pix_mask;
                     atomicAdd(&s_acc[wave][0][slot], L.x);  // Scene.cpp:148
                     atomicAdd(&s_acc[wave][1][slot], L.y);

@@ -109,6 +109,17 @@ struct alignas(32) Light {
     uint32_t pad;
 };
 
+// Light trees and general light shapes (kernels instantiated with kLightTree only): the entry's
+// place in the tree and its transform chain, index-aligned with Light[].
+struct alignas(32) LightNode {
+    uint32_t first, count;          // RTX_LIGHT_LIST: children are entries [first, first + count)
+    uint32_t step_begin, step_end;  // leaf: transform chain, outermost wrapper first
+    float weight;                   // product of the 1 / n of every list above the entry
+    uint32_t pad[3];
+};
+constexpr uint32_t kLightsGeneral = 1u;  // SceneView::light_flags: RTX_LIGHTS_GENERAL semantics
+constexpr uint32_t kLightsTree = 2u;     // nested lists, chains or XY / YZ rect lights present: tree kernels
+
 // BVH over top-level items (a bare primitive, or one transformed instance such as a Box under
 // Rotate / Translate).  A node holds the boxes of BOTH its children, so one 64-byte fetch
 // decides two subtrees.  A child reference is either the index of another node or, with
@@ -163,6 +174,9 @@ struct SceneView {
     const BvhFastItem* bvh_fast;  // the same items as fast-mode leaf records
     uint32_t n_prims, n_groups, n_steps, n_materials, n_textures, n_lights, n_bvh_nodes;
     uint32_t light_is_list;
+    const LightNode* light_nodes;  // n_light_entries records
+    uint32_t n_light_entries;      // all entries of lights[] / light_nodes[]; n_lights = the top-level ones
+    uint32_t light_flags;          // kLights*
     float cam_origin[3], cam_ll[3], cam_u[3], cam_v[3];
     float background[3];
     uint32_t background_mode;  // RTX_BACKGROUND_*

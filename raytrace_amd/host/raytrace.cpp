@@ -94,13 +94,29 @@ uint32_t FlatScene::add_prim(uint32_t kind, float a, float b, float c, float d, 
     return (uint32_t)prim_kind.size() - 1;
 }
 
-void FlatScene::add_light(uint32_t kind, float a, float b, float c, float d, float e) {
-    light_kind.push_back(kind);
-    light_a.push_back(a);
-    light_b.push_back(b);
-    light_c.push_back(c);
-    light_d.push_back(d);
-    light_e.push_back(e);
+uint32_t FlatScene::reserve_lights(uint32_t n) {
+    const uint32_t first = (uint32_t)light_kind.size();
+    light_kind.resize(first + n, RTX_LIGHT_OTHER);
+    for (std::vector<uint32_t>* v : {&light_first, &light_count, &light_chain}) v->resize(first + n, 0u);
+    for (std::vector<float>* v : {&light_a, &light_b, &light_c, &light_d, &light_e}) v->resize(first + n, 0.0f);
+    return first;
+}
+
+void FlatScene::set_light(uint32_t slot, uint32_t kind, float a, float b, float c, float d, float e, Cursor& cur) {
+    light_kind[slot] = kind;
+    light_a[slot] = a;
+    light_b[slot] = b;
+    light_c[slot] = c;
+    light_d[slot] = d;
+    light_e[slot] = e;
+    // only general light sampling looks at a light's transforms (and only it lets them be recorded)
+    light_chain[slot] = m_general_lights && kind != RTX_LIGHT_OTHER ? (uint32_t)intern_chain(cur) : 0u;
+}
+
+void FlatScene::set_light_list(uint32_t slot, uint32_t first, uint32_t count) {
+    light_kind[slot] = RTX_LIGHT_LIST;
+    light_first[slot] = first;
+    light_count[slot] = count;
 }
 
 uint32_t FlatScene::intern_material(const MaterialPtr& m) {
@@ -198,7 +214,12 @@ const RtxScene* FlatScene::view() {
     s.tex_offset = tex_offset.data();
     s.n_texel_bytes = texels.size();
     s.texels = texels.data();
-    s.n_lights = (uint32_t)light_kind.size();
+    s.n_lights = n_top_lights;
+    s.n_light_entries = (uint32_t)light_kind.size();
+    s.light_sampling = m_general_lights ? RTX_LIGHTS_GENERAL : RTX_LIGHTS_REFERENCE;
+    s.light_first = light_first.data();
+    s.light_count = light_count.data();
+    s.light_chain = light_chain.data();
     s.light_is_list = m_light_is_list ? 1u : 0u;
     s.light_kind = light_kind.data();
     s.light_a = light_a.data();
@@ -322,17 +343,18 @@ uint32_t DiffuseLight::flatten(FlatScene& f) const {
 void Sphere::flatten(FlatScene& f, FlatScene::Cursor& cur) const {
     f.add_prim(RTX_PRIM_SPHERE, m_center.getX(), m_center.getY(), m_center.getZ(), m_radius, 0.0f, m_material, cur);
 }
-void Sphere::flatten_light(FlatScene& f) const {
-    f.add_light(RTX_LIGHT_SPHERE, m_center.getX(), m_center.getY(), m_center.getZ(), m_radius, 0.0f);
+void Sphere::flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const {
+    f.set_light(slot, RTX_LIGHT_SPHERE, m_center.getX(), m_center.getY(), m_center.getZ(), m_radius, 0.0f, cur);
 }
 
 void Rect::flatten(FlatScene& f, FlatScene::Cursor& cur) const {
     f.add_prim((uint32_t)m_axis, m_x0, m_x1, m_y0, m_y1, m_k, m_material, cur);
 }
-void Rect::flatten_light(FlatScene& f) const {
-    // Rect::pdf_value / random only act for kXZ (Rect.cpp:37,51); the kernel treats
-    // the other two axes like any shape that keeps the defaults.
-    f.add_light((uint32_t)m_axis, m_x0, m_x1, m_y0, m_y1, m_k);
+void Rect::flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const {
+    // Rect::pdf_value / random only act for kXZ (Rect.cpp:37,51); unless the scene asks for
+    // general light sampling the kernel treats the other two axes like any shape that keeps
+    // the defaults.
+    f.set_light(slot, (uint32_t)m_axis, m_x0, m_x1, m_y0, m_y1, m_k, cur);
 }
 
 void ShapeList::flatten(FlatScene& f, FlatScene::Cursor& cur) const {
@@ -341,13 +363,25 @@ void ShapeList::flatten(FlatScene& f, FlatScene::Cursor& cur) const {
         p->flatten(f, cur);
     }
 }
-void ShapeList::flatten_light(FlatScene& f) const {
-    f.fail("a ShapeList nested inside the light list is not supported by the GPU path");
+void ShapeList::flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const {
+    if (m_list.empty()) {
+        f.fail("an empty ShapeList inside the light shape (undefined behaviour in the reference, ShapeList.cpp:28-35)");
+        return;
+    }
+    const uint32_t first = f.reserve_lights((uint32_t)m_list.size());
+    f.set_light_list(slot, first, (uint32_t)m_list.size());
+    for (size_t k = 0; k < m_list.size(); ++k) {
+        if (!m_list[k]) { f.fail("light list holds a null shape"); continue; }
+        m_list[k]->flatten_light(f, first + (uint32_t)k, cur);
+    }
 }
 void ShapeList::flatten_as_light_list(FlatScene& f) const {
-    for (const ShapePtr& p : m_list) {
-        if (!p) { f.fail("light list holds a null shape"); continue; }
-        p->flatten_light(f);
+    const uint32_t first = f.reserve_lights((uint32_t)m_list.size());  // 0: the top-level entries come first
+    f.n_top_lights = (uint32_t)m_list.size();
+    FlatScene::Cursor cur;
+    for (size_t k = 0; k < m_list.size(); ++k) {
+        if (!m_list[k]) { f.fail("light list holds a null shape"); continue; }
+        m_list[k]->flatten_light(f, first + (uint32_t)k, cur);
     }
 }
 
@@ -368,6 +402,14 @@ Box::Box(const Vector3& p0, const Vector3& p1, const MaterialPtr& m)
     }
 }
 void Box::flatten(FlatScene& f, FlatScene::Cursor& cur) const { m_list->flatten(f, cur); }
+// Box, FlipNormals, Translate and Rotate keep Shape's default pdf_value() / random() in the
+// reference (Box.h, FlipNormals.h, Translate.h, Rotate.h override hit() only).  With general
+// light sampling they pass the query on: a box is the list of its six faces, a flip changes
+// nothing (the densities use |cos|), a translation / rotation joins the leaf's chain.
+void Box::flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const {
+    if (f.general_lights()) m_list->flatten_light(f, slot, cur);
+    else Shape::flatten_light(f, slot, cur);
+}
 
 void FlipNormals::flatten(FlatScene& f, FlatScene::Cursor& cur) const {
     if (!m_shape) { f.fail("FlipNormals wraps a null shape"); return; }
@@ -376,6 +418,29 @@ void FlipNormals::flatten(FlatScene& f, FlatScene::Cursor& cur) const {
     cur.flip = !cur.flip;
     m_shape->flatten(f, cur);
     cur.flip = !cur.flip;
+}
+
+void FlipNormals::flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const {
+    if (f.general_lights() && m_shape) m_shape->flatten_light(f, slot, cur);
+    else Shape::flatten_light(f, slot, cur);
+}
+
+void Translate::flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const {
+    if (!f.general_lights() || !m_shape) { Shape::flatten_light(f, slot, cur); return; }
+    FlatScene::Cursor inner;
+    inner.steps = cur.steps;
+    inner.steps.push_back({RTX_STEP_TRANSLATE, m_offset.getX(), m_offset.getY(), m_offset.getZ(), 0.0f});
+    inner.chain = -1;
+    m_shape->flatten_light(f, slot, inner);
+}
+
+void Rotate::flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const {
+    if (!f.general_lights() || !m_shape) { Shape::flatten_light(f, slot, cur); return; }
+    FlatScene::Cursor inner;
+    inner.steps = cur.steps;
+    inner.steps.push_back({RTX_STEP_ROTATE, m_quat.x, m_quat.y, m_quat.z, m_quat.w});
+    inner.chain = -1;
+    m_shape->flatten_light(f, slot, inner);
 }
 
 void Translate::flatten(FlatScene& f, FlatScene::Cursor& cur) const {
@@ -569,6 +634,7 @@ bool Scene::flatten(FlatScene& out) const {
     }
     FlatScene::Cursor cur;
     m_world->flatten(out, cur);
+    out.set_general_lights(m_generalLights);
     if (!m_light) {
         // no light shape at all: diffuse bounces sample the material's own pdf only (an
         // extension; the reference's color() dereferences its light unconditionally)
@@ -580,7 +646,9 @@ bool Scene::flatten(FlatScene& out) const {
             out.fail("the light list is empty (undefined behaviour in the reference, ShapeList.cpp:28-35)");
     } else {
         out.set_light_is_list(false);
-        m_light->flatten_light(out);
+        out.n_top_lights = 1;
+        FlatScene::Cursor lcur;
+        m_light->flatten_light(out, out.reserve_lights(1), lcur);
     }
     if (out.prim_kind.empty()) out.fail("the world has no primitives");
     out.set_camera(*m_camera);

@@ -113,7 +113,14 @@ public:
 
     uint32_t add_prim(uint32_t kind, float a, float b, float c, float d, float e, const MaterialPtr& m,
                       Cursor& cur);
-    void add_light(uint32_t kind, float a, float b, float c, float d, float e);
+    // Light entries.  The entries of one list are contiguous: reserve them first, then fill
+    // each slot (a nested list reserves its own children behind them).
+    uint32_t reserve_lights(uint32_t n);
+    void set_light(uint32_t slot, uint32_t kind, float a, float b, float c, float d, float e, Cursor& cur);
+    void set_light_list(uint32_t slot, uint32_t first, uint32_t count);
+    // RTX_LIGHTS_GENERAL: rects of every axis and wrapped shapes are sampled as lights
+    void set_general_lights(bool g) { m_general_lights = g; }
+    bool general_lights() const { return m_general_lights; }
     uint32_t intern_material(const MaterialPtr& m);
     uint32_t intern_texture(const TexturePtr& t);
     uint32_t new_texture(uint32_t kind, float r, float g, float b, uint32_t odd, uint32_t even);
@@ -136,13 +143,15 @@ public:
     std::vector<uint32_t> tex_kind, tex_odd, tex_even, tex_offset;
     std::vector<uint8_t> texels;
     std::vector<float> tex_r, tex_g, tex_b;
-    std::vector<uint32_t> light_kind;
+    std::vector<uint32_t> light_kind, light_first, light_count, light_chain;
     std::vector<float> light_a, light_b, light_c, light_d, light_e;
+    uint32_t n_top_lights = 0;
 
 private:
     int intern_chain(Cursor& cur);
     RtxScene m_view;
     bool m_light_is_list = true;
+    bool m_general_lights = false;
     float m_cam[4][3];
     float m_background[3];
     bool m_background_sky = false;
@@ -256,10 +265,13 @@ public:
     virtual ~Shape() {}
     // Emit this shape's leaves, in the order the reference's hit() visits them.
     virtual void flatten(FlatScene& f, FlatScene::Cursor& cur) const = 0;
-    // Emit this shape as ONE entry of a light list.  Only Rect and Sphere override
-    // pdf_value() / random() in the reference (Shape.h:8-9); everything else keeps
-    // the defaults.
-    virtual void flatten_light(FlatScene& f) const { f.add_light(RTX_LIGHT_OTHER, 0, 0, 0, 0, 0); }
+    // Emit this shape as entry `slot` of the light arrays.  Only Rect, Sphere and ShapeList
+    // override pdf_value() / random() in the reference (Shape.h:8-9); everything else keeps
+    // the defaults, unless the scene asks for general light sampling, in which case the
+    // wrappers pass the query on to the shape they wrap (`cur` carries their transforms).
+    virtual void flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const {
+        f.set_light(slot, RTX_LIGHT_OTHER, 0, 0, 0, 0, 0, cur);
+    }
     virtual bool is_list() const { return false; }
 };
 
@@ -268,7 +280,7 @@ public:
     Sphere() : m_radius(0) {}
     Sphere(const Vector3& c, float r, const MaterialPtr& mat) : m_center(c), m_radius(r), m_material(mat) {}
     void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
-    void flatten_light(FlatScene& f) const override;
+    void flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const override;
 
 private:
     Vector3 m_center;
@@ -283,7 +295,7 @@ public:
     Rect(float x0, float x1, float y0, float y1, float k, AxisType axis, const MaterialPtr& m)
         : m_x0(x0), m_x1(x1), m_y0(y0), m_y1(y1), m_k(k), m_axis(axis), m_material(m) {}
     void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
-    void flatten_light(FlatScene& f) const override;
+    void flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const override;
 
 private:
     float m_x0, m_x1, m_y0, m_y1, m_k;
@@ -297,9 +309,10 @@ public:
     void add(const ShapePtr& shape) { m_list.push_back(shape); }
     size_t size() const { return m_list.size(); }
     void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
-    void flatten_light(FlatScene& f) const override;
+    // a list nested inside the light shape: one RTX_LIGHT_LIST entry + its children
+    void flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const override;
     bool is_list() const override { return true; }
-    // Emit the entries of this list as the scene's light list.
+    // Emit the entries of this list as the scene's top-level light list.
     void flatten_as_light_list(FlatScene& f) const;
 
 private:
@@ -311,6 +324,7 @@ public:
     Box() {}
     Box(const Vector3& p0, const Vector3& p1, const MaterialPtr& m);
     void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
+    void flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const override;
 
 private:
     Vector3 m_p0, m_p1;
@@ -321,6 +335,7 @@ class FlipNormals : public Shape {
 public:
     FlipNormals(const ShapePtr& shape) : m_shape(shape) {}
     void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
+    void flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const override;
 
 private:
     ShapePtr m_shape;
@@ -330,6 +345,7 @@ class Translate : public Shape {
 public:
     Translate(const ShapePtr& sp, const Vector3& displacement) : m_shape(sp), m_offset(displacement) {}
     void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
+    void flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const override;
 
 private:
     ShapePtr m_shape;
@@ -341,6 +357,7 @@ public:
     Rotate(const ShapePtr& sp, const Vector3& axis, float angle)
         : m_shape(sp), m_quat(Quat::rotation(radians(angle), axis)) {}
     void flatten(FlatScene& f, FlatScene::Cursor& cur) const override;
+    void flatten_light(FlatScene& f, uint32_t slot, FlatScene::Cursor& cur) const override;
 
 private:
     ShapePtr m_shape;
@@ -437,6 +454,10 @@ public:
     // color() never calls it.  setBackgroundSky(true) makes misses return it.
     Vector3 backgroundSky(const Vector3& d) const;
     void setBackgroundSky(bool sky) { m_backgroundSky = sky; }
+    // An extension: sample rects of every axis and flipped / translated / rotated shapes and
+    // boxes as lights.  The reference gives all of these the defaults of Shape.h:8-9 (density 0,
+    // direction (1,0,0)), which stays the behaviour unless this is switched on.
+    void setGeneralLightSampling(bool g) { m_generalLights = g; }
 
     // render options the reference fixes at compile time
     void setMaxDepth(int d) { m_maxDepth = d; }          // MAX_DEPTH, Scene.cpp:9
@@ -462,6 +483,7 @@ protected:
     int m_samples;
     std::unique_ptr<Shape> m_light;
     bool m_backgroundSky = false;
+    bool m_generalLights = false;
     int m_maxDepth = 50;
     uint64_t m_seed = 0;
     bool m_deterministic = false;

@@ -35,6 +35,7 @@ struct NamedScene : public Scene {
         setLight(parts.light);
         setBackground(parts.background);
         setBackgroundSky(parts.sky);
+        setGeneralLightSampling(parts.general_lights);
     }
     bool built() const { return m_built; }
 

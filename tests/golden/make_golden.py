@@ -34,11 +34,15 @@ SAMPLE_CASES = [  # scene, w, h, spp_begin, spp, seed
     ("bvh_stress_500", 24, 14, 0, 2, 7),
     ("textured", 48, 27, 0, 8, 7),
     ("sky_spheres", 48, 27, 0, 8, 7),  # no light shape + sky: from the CPU restatement (see RESTATEMENT_ONLY)
+    ("cornell_light_tree", 48, 27, 0, 8, 7),   # nested light lists, XY rect / wrapped shapes with the default density
+    ("cornell_side_lights", 48, 27, 0, 8, 7),  # general light sampling: from the CPU restatement
 ]
 # Scenes the reference's color() cannot render (it dereferences its light, Scene.cpp:113, and
 # never calls backgroundSky): their vectors come from oracle/restate.cpp, whose pieces for this
 # mode are pinned against the reference function by function (sky_and_cosine_pdf.npz).
-RESTATEMENT_ONLY = ("sky_spheres",)
+# Likewise general light sampling (XY / YZ rect, flipped / rotated / translated lights, a box):
+# the reference gives these shapes density 0 and direction (1,0,0) (Rect.cpp:37,51, Shape.h:8-9).
+RESTATEMENT_ONLY = ("sky_spheres", "cornell_side_lights")
 HIT_SCENES = ("cornell", "cornell_extra", "random_field", "bvh_stress_500", "textured")  # + sky_spheres needs no hits: same shapes
 TEXTURE = os.path.join(HERE, "texture_64x32.bmp")
 

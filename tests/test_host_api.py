@@ -31,7 +31,32 @@ def test_struct_layout_matches_header():
     assert api.HIT_DTYPE.itemsize == 48
     assert ctypes.sizeof(api.RtxSceneInfo) == 16
     assert api.RtxScene.cam_origin.offset % 4 == 0
-    assert ctypes.sizeof(api.RtxScene) == 8 + 9 * 8 + 8 + 8 + 8 + 5 * 8 + 8 + 3 * 8 + 8 + 7 * 8 + 8 + 8 + 8 + 6 * 8 + 15 * 4 + 4
+
+
+def test_struct_layout_matches_the_compiled_header(tmp_path):
+    """sizeof / offsetof of every struct of include/rtx.h as gcc lays them out against the ctypes mirrors."""
+    import subprocess
+
+    structs = {"RtxScene": api.RtxScene, "RtxParams": api.RtxParams, "RtxHit": api.RtxHit,
+               "RtxSceneInfo": api.RtxSceneInfo}
+    lines = []
+    for name, cls in structs.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for field, _ in cls._fields_:
+            lines.append(f'printf("{name}.{field} %zu\\n", offsetof({name}, {field}));')
+    src = tmp_path / "layout.c"
+    src.write_text("#include <stdio.h>\n#include <stddef.h>\n#include \"rtx.h\"\nint main(void) {\n"
+                   + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True,
+                                                       text=True).stdout.splitlines())
+    for name, cls in structs.items():
+        assert int(got[name]) == ctypes.sizeof(cls), name
+        for field, _ in cls._fields_:
+            assert int(got[f"{name}.{field}"]) == getattr(cls, field).offset, (name, field)
+    assert api.RTX_ABI_VERSION == int(re.search(r"#define RTX_ABI_VERSION (\d+)u", open(
+        os.path.join(ROOT, "include", "rtx.h")).read()).group(1))
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback():
@@ -157,6 +182,40 @@ def test_missing_texture_file_is_an_error(tmp_path, monkeypatch):
     monkeypatch.setenv("RTX_TEXTURE", str(tmp_path / "junk.bmp"))
     with pytest.raises(ValueError):
         api.HostScene("textured", 16, 9)
+
+
+def test_light_tree_flattening():
+    """A ShapeList nested in the light list becomes an RTX_LIGHT_LIST entry whose children lie behind
+    the top-level entries; wrapped shapes keep Shape's defaults (Shape.h:8-9) in reference sampling."""
+    s = api.HostScene("cornell_light_tree", 32, 18)
+    a = s.arrays()
+    L, O = api.RTX_LIGHT_LIST, api.RTX_LIGHT_OTHER
+    assert int(a["n_lights"][0]) == 5 and int(a["light_sampling"][0]) == api.RTX_LIGHTS_REFERENCE
+    # top level: XZ rect, nested list, XY rect, translated sphere (default), box (default);
+    # then the nested list's three entries, then the innermost list's one
+    assert a["light_kind"].tolist() == [1, L, 0, O, O, 1, 3, L, 1]
+    assert (int(a["light_first"][1]), int(a["light_count"][1])) == (5, 3)
+    assert (int(a["light_first"][7]), int(a["light_count"][7])) == (8, 1)
+    assert not a["light_chain"].any()
+
+
+def test_general_light_flattening():
+    """General light sampling: flips vanish, Translate / Rotate become the leaf's chain, a Box is the
+    list of its six faces (Box.cpp:15-28)."""
+    s = api.HostScene("cornell_side_lights", 32, 18)
+    a = s.arrays()
+    L = api.RTX_LIGHT_LIST
+    assert int(a["light_sampling"][0]) == api.RTX_LIGHTS_GENERAL and int(a["n_lights"][0]) == 3
+    assert a["light_kind"].tolist() == [2, 0, L, 0, 0, 1, 1, 2, 2]
+    assert (int(a["light_first"][2]), int(a["light_count"][2])) == (3, 6)
+    chains = a["light_chain"].tolist()
+    assert chains[:3] == [0, 0, 0] and len(set(chains[3:])) == 1 and chains[3] != 0
+    c = chains[3]
+    steps = a["step_kind"][a["chain_begin"][c]:a["chain_begin"][c + 1]].tolist()
+    assert steps == [0, 1]  # outermost first: the translation, then the rotation
+    # the same scene without a light shape
+    b = api.HostScene("cornell_side_lights_nolight", 32, 18).arrays()
+    assert b["light_kind"].size == 0 and np.array_equal(a["prim_kind"], b["prim_kind"])
 
 
 def test_scene_without_light_and_with_sky_background():

@@ -83,6 +83,21 @@ def test_restatement_sky_and_cosine_pdf_match_reference():
     assert (vals > 0).all()
 
 
+def test_restatement_general_light_sampling_is_unbiased():
+    """General light sampling (rects of every axis, rotated / translated / boxed lights) is an
+    extension the reference cannot check: its own contract is that it leaves the expectation of
+    the estimator alone.  Against the same scene rendered with the material's pdf only."""
+    w, h = 64, 36
+    lit = restate.render(api.HostScene("cornell_side_lights", w, h), w, h, 0, 1024, seed=1, threads=8)["sum"] / 1024
+    unlit = restate.render(api.HostScene("cornell_side_lights_nolight", w, h), w, h, 0, 4096, seed=2, threads=8)["sum"] / 4096
+    assert abs(lit.mean() / unlit.mean() - 1) < 0.01
+
+    def blocks(x):
+        return x.reshape(6, 6, 8, 8, 3).mean(axis=(1, 3))
+
+    assert np.abs(blocks(lit) - blocks(unlit)).max() < 0.15 * blocks(unlit).mean()
+
+
 def test_restatement_image_write_matches_reference():
     g = util.load_golden("image_write")
     assert np.array_equal(restate.image_write(g["rgb"]), g["rgb8"])
@@ -139,7 +154,7 @@ def test_builtin_scene_equals_transcribed_scene():
 @needs_ref
 def test_reference_and_restatement_agree_on_fresh_inputs():
     for name, w, h, spp, seed in (("cornell_extra", 36, 20, 6, 1234), ("random_field", 30, 16, 3, 99),
-                                  ("textured", 40, 22, 5, 31)):
+                                  ("textured", 40, 22, 5, 31), ("cornell_light_tree", 40, 22, 6, 5)):
         scene = api.HostScene(name, w, h)
         a = restate.render(scene, w, h, 10, spp, seed=seed, threads=4, per_sample=True)
         b = ref.RefScene(name, w, h).render(10, spp, seed=seed, threads=4, per_sample=True)
