@@ -8,7 +8,8 @@ the whole frame (default workload: the reference Cornell box at 1920x1080,
 512 spp per GPU per step — with 8 GPUs one step is the 4096-spp frame of the
 headline configuration, with one GPU it is one GPU's share of it), followed for
 N > 1 by the RCCL sum-reduce of the fp32 accumulators to rank 0 and, on rank 0,
-the resolve to 8 bits.  Ranks render disjoint absolute sample ranges (weak
+the resolve to 8 bits; reduce and resolve of a step run on a second stream while the next
+step renders (two accumulators alternate).  Ranks render disjoint absolute sample ranges (weak
 scaling: per-GPU work is fixed); the random stream is keyed by the absolute
 sample index, so the image does not depend on N beyond fp32 summation order.
 
@@ -139,7 +140,7 @@ def main() -> int:
     import torch.distributed as dist
 
     from raytrace_amd import api
-    from raytrace_amd.distributed import step_sample_range
+    from raytrace_amd.distributed import run_pipelined_steps, step_sample_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -162,47 +163,51 @@ def main() -> int:
     ctx.upload(scene, api.RTX_ACCEL_AUTO)
     info = ctx.info()
 
-    step_accum = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)   # this step, this GPU
+    step_accum = [torch.zeros((h, w, 3), dtype=torch.float32, device=dev) for _ in range(2)]  # this GPU's steps
     frame_accum = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)  # rank 0: running frame
     rays = torch.zeros(1, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
+    render_stream = torch.cuda.current_stream(dev)
+    side_stream = torch.cuda.Stream(dev)  # reduce + resolve of step k while step k+1 renders
+    ev = {}
 
     total_spp_done = 0
 
-    def one_step(k: int, timed_idx: int | None):
-        nonlocal total_spp_done
+    def render(k: int, buf):
         begin, _ = step_sample_range(k, rank, world, spp)
         p = ctx.params(w, h, begin, spp, mode=mode, seed=0, accumulate=False)
-        if timed_idx is not None:
-            ev[timed_idx][0].record(stream)
-        ctx.render_device(p, step_accum.data_ptr(), rays.data_ptr(), stream.cuda_stream)
-        if timed_idx is not None:
-            ev[timed_idx][1].record(stream)
+        timed = k >= args.warmup
+        if timed:
+            ev[k] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[k][0].record(render_stream)  # on the stream the kernel is launched on
+        ctx.render_device(p, buf.data_ptr(), rays.data_ptr(), render_stream.cuda_stream)
+        if timed:
+            ev[k][1].record(render_stream)
+
+    def combine(k: int, buf):
+        nonlocal total_spp_done
         if world > 1:
-            dist.reduce(step_accum, dst=0, op=dist.ReduceOp.SUM)
+            dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
         total_spp_done += spp * world
         if rank == 0:
-            frame_accum.add_(step_accum)
-            return ctx.resolve_device(w, h, total_spp_done, frame_accum.data_ptr(), stream.cuda_stream)
+            frame_accum.add_(buf)
+            return ctx.resolve_device(w, h, total_spp_done, frame_accum.data_ptr(), side_stream.cuda_stream)
         return None
 
-    for k in range(args.warmup):
-        one_step(k, None)
+    run_pipelined_steps(range(args.warmup), render, combine, step_accum, render_stream, side_stream)
+    torch.cuda.synchronize(dev)
     rays.zero_()
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    image = None
-    for k in range(args.steps):
-        image = one_step(args.warmup + k, k)
+    images = run_pipelined_steps(range(args.warmup, args.warmup + args.steps), render, combine, step_accum,
+                                 render_stream, side_stream)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    image = images[-1] if images else None
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rays_total = rays.clone()
@@ -212,7 +217,7 @@ def main() -> int:
     elapsed = float(el.item())
     n_rays = int(rays_total.item())
     my_rays = int(rays.item())
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms = [a.elapsed_time(b) for a, b in ev.values()]
 
     if rank == 0:
         samples = w * h * spp * world * args.steps
@@ -243,7 +248,8 @@ def main() -> int:
                 "max_depth": 50,
                 "mode": args.mode,
                 "accel": "bvh" if info.accel == api.RTX_ACCEL_BVH else "linear",
-                "parallelism": f"spp-split x{world}, reduce(sum) of fp32 accumulators to rank 0 per step",
+                "parallelism": f"spp-split x{world}, reduce(sum) of fp32 accumulators to rank 0 per step, "
+                               "overlapped with the next step's rendering",
             },
             "spp_per_s": spp * world * args.steps / elapsed,
             "msamples_per_s": samples / elapsed / 1e6,

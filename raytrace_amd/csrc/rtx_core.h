@@ -614,7 +614,8 @@ RTX_DEV bool slab(const float lo[3], const float hi[3], V3 inv, V3 noi, float t0
 
 // Next deferred subtree of this lane, or 0xffffffff when its stack is empty.  An entry that
 // did not fit (the builder bounds the depth, so this does not happen) reads as an empty leaf.
-RTX_DEV uint32_t pop_ref(uint32_t (*stack)[256], uint32_t& sp, uint32_t tid) {
+template <int kCols>
+RTX_DEV uint32_t pop_ref(uint32_t (*stack)[kCols], uint32_t& sp, uint32_t tid) {
     if (sp == 0u) return 0xffffffffu;
     --sp;
     return sp < (uint32_t)kBvhStack ? stack[sp][tid] : kBvhLeaf;
@@ -1398,17 +1399,26 @@ constexpr uint32_t kShadeBatch = RTX_SHADE_BATCH;
 #define RTX_LEAF_BATCH 16
 #endif
 constexpr uint32_t kLeafBatch = RTX_LEAF_BATCH;
+// One wave per block: a block's LDS and wave slots are free as soon as ITS pool is spent (the
+// waves of a 256-thread block wait for the slowest of the four), and the per-lane stack is 6 KB
+// per wave, so LDS no longer bounds the occupancy.
+#ifndef RTX_BVH_BLOCK
+#define RTX_BVH_BLOCK 64
+#endif
+#ifndef RTX_BVH_WAVES
+#define RTX_BVH_WAVES 5  // minimum resident waves per SIMD the kernel is compiled for
+#endif
 
 template <bool kLightTree>
-__global__ void __launch_bounds__(RTX_BLOCK, RTX_TRACE_WAVES_BVH) trace_bvh_kernel(const TraceArgs a) {
-    __shared__ float s_acc[RTX_BLOCK / 64][3][64];
-    __shared__ uint32_t s_stack[kBvhStack][RTX_BLOCK];
+__global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel(const TraceArgs a) {
+    __shared__ float s_acc[RTX_BVH_BLOCK / 64][3][64];
+    __shared__ uint32_t s_stack[kBvhStack][RTX_BVH_BLOCK];
     const SceneView& sc = a.scene;
     const uint32_t tid = threadIdx.x, lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t twl = a.tile_w_log2, pixl = a.tile_w_log2 + a.tile_h_log2;
     const uint32_t tile_w = 1u << twl, tile_h = 1u << a.tile_h_log2, pix_mask = (1u << pixl) - 1u;
-    constexpr uint32_t kSide = RTX_BLOCK == 256 ? 2u : 1u;
+    constexpr uint32_t kSide = RTX_BVH_BLOCK == 256 ? 2u : 1u;
     const uint32_t tiles_x = (a.width + kSide * tile_w - 1u) / (kSide * tile_w);
     const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
     const uint32_t x0 = (kSide * bx + (wave & (kSide - 1u))) * tile_w;

@@ -7,7 +7,7 @@ rank 0 combines them.  There is no other exchange step.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Tuple
+from typing import Callable, List, Sequence, Tuple
 
 
 def split_samples(total_spp: int, world: int) -> List[Tuple[int, int]]:
@@ -47,3 +47,55 @@ def render_frame(render_range: Callable[[int, int], "object"], total_spp: int, r
         else:
             reduce_to_root(accum)
     return accum
+
+
+def run_pipelined_steps(steps: Sequence[int], render: Callable[[int, "object"], None],
+                        combine: Callable[[int, "object"], "object"], buffers: Sequence["object"],
+                        render_stream=None, side_stream=None) -> list:
+    """Progressive steps with the exchange of step k hidden behind the rendering of step k+1.
+
+    `render(step, buf)` enqueues the rendering of `step` into the accumulator `buf`;
+    `combine(step, buf)` sum-reduces `buf` to rank 0 and consumes it there (adds it to the
+    running frame, resolves); its return values are collected.  Two accumulators alternate, and
+    the rendering of the next step is enqueued BEFORE the current step is combined, so the GPU
+    renders while the previous step's accumulator travels over xGMI and is resolved.  With
+    streams (GPU) `render` runs on `render_stream`, `combine` on `side_stream`, ordered by
+    events in both directions (a buffer is not rendered into again before its last combine has
+    finished); without streams (CPU tensors, gloo) the same order runs synchronously.
+    """
+    if len(buffers) != 2:
+        raise ValueError("two accumulators alternate")
+    steps = list(steps)
+    cuda = render_stream is not None
+    if cuda:
+        import torch
+    rendered = [None, None]
+    combined = [None, None]
+
+    def launch(i: int) -> None:
+        b = i % 2
+        if cuda:
+            if combined[b] is not None:
+                render_stream.wait_event(combined[b])
+            with torch.cuda.stream(render_stream):
+                render(steps[i], buffers[b])
+            rendered[b] = render_stream.record_event()
+        else:
+            render(steps[i], buffers[b])
+
+    out = []
+    if not steps:
+        return out
+    launch(0)
+    for i, step in enumerate(steps):
+        if i + 1 < len(steps):
+            launch(i + 1)
+        b = i % 2
+        if cuda:
+            side_stream.wait_event(rendered[b])
+            with torch.cuda.stream(side_stream):
+                out.append(combine(step, buffers[b]))
+            combined[b] = side_stream.record_event()
+        else:
+            out.append(combine(step, buffers[b]))
+    return out

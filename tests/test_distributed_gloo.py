@@ -44,6 +44,21 @@ def test_step_ranges_tile_the_sample_axis():
         rd.step_sample_range(0, 4, 4, 1)
 
 
+def test_pipelined_steps_order_and_buffers():
+    """render(k+1) is issued before combine(k); the two accumulators alternate; a buffer is
+    combined before it is rendered into again."""
+    log = []
+    buffers = ["A", "B"]
+    out = rd.run_pipelined_steps([3, 4, 5, 6], lambda k, b: log.append(("render", k, b)),
+                                 lambda k, b: log.append(("combine", k, b)) or k * 10, buffers)
+    assert out == [30, 40, 50, 60]
+    assert log == [("render", 3, "A"), ("render", 4, "B"), ("combine", 3, "A"), ("render", 5, "A"),
+                   ("combine", 4, "B"), ("render", 6, "B"), ("combine", 5, "A"), ("combine", 6, "B")]
+    assert rd.run_pipelined_steps([], None, None, buffers) == []
+    with pytest.raises(ValueError):
+        rd.run_pipelined_steps([0], None, None, ["only one"])
+
+
 def _worker(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
     import torch
@@ -64,13 +79,21 @@ def _worker(rank, world, port, out_path):
 
     acc = distributed.render_frame(render_range, total, rank, world)
     # progressive (weak) variant: 2 steps of 2 spp per rank, reduced every step
+    # (the loop bench.py runs: the next step is rendered before the current one is reduced)
     frame = torch.zeros((h, w, 3))
-    for step in range(2):
+    buffers = [torch.zeros((h, w, 3)), torch.zeros((h, w, 3))]
+
+    def render(step, buf):
         b, n = distributed.step_sample_range(step, rank, world, 2)
-        part = render_range(b, n)
-        dist.reduce(part, dst=0, op=dist.ReduceOp.SUM)
+        buf.copy_(render_range(b, n))
+
+    def combine(step, buf):
+        dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
         if rank == 0:
-            frame += part
+            frame.add_(buf)
+        return step
+
+    assert distributed.run_pipelined_steps(range(2), render, combine, buffers) == [0, 1]
     if rank == 0:
         np.savez(out_path, strong=acc.numpy(), weak=frame.numpy())
     dist.barrier()
