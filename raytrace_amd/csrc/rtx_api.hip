@@ -76,6 +76,7 @@ struct RtxContext {
     DeviceArray<rtxd::ScanRec> scan_recs;
     DeviceArray<rtxd::ScanHit> scan_info;
     DeviceArray<rtxd::BvhFastItem> bvh_fast;
+    DeviceArray<rtxd::BvhMap> bvh_maps;
     DeviceArray<uint32_t> scan_orig;
     DeviceArray<rtxd::BvhNode> bvh;
     DeviceArray<rtxd::Group> bvh_items;
@@ -317,7 +318,8 @@ void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rt
 // in their slot order.
 void build_bvh_fast_items(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::PrimInfo>& info,
                           const std::vector<rtxd::Group>& items, const std::vector<rtxd::Step>& steps,
-                          std::vector<rtxd::BvhFastItem>& out, std::vector<rtxd::ScanHit>& si, std::vector<uint32_t>& so) {
+                          std::vector<rtxd::BvhFastItem>& out, std::vector<rtxd::BvhMap>& maps,
+                          std::vector<rtxd::ScanHit>& si, std::vector<uint32_t>& so) {
     std::vector<char> used(prims.size(), 0);
     for (uint32_t g = 0; g < items.size(); ++g) {
         const rtxd::Group& G = items[g];
@@ -336,30 +338,34 @@ void build_bvh_fast_items(const std::vector<rtxd::Prim>& prims, const std::vecto
         if (n == 6) boxes = find_boxes(prims, G.prim_begin, G.prim_end, used);
         if (n == 1 && S.identity) {
             const rtxd::Prim& P = prims[G.prim_begin];
-            I.type = P.kind_flip & 3u;  // kBvhItemRect* / kBvhItemSphere = RTX_PRIM_*
+            const uint32_t type = P.kind_flip & 3u;  // kBvhItemRect* / kBvhItemSphere = RTX_PRIM_*
+            I.type_count = type | (1u << 8);
             I.f[0] = P.a; I.f[1] = P.b; I.f[2] = P.c;
-            I.f[3] = I.type == rtxd::kBvhItemSphere ? P.d * P.d : P.d;
+            I.f[3] = type == rtxd::kBvhItemSphere ? P.d * P.d : P.d;
             I.f[4] = P.e;
-            I.count = 1;
             push(G.prim_begin);
         } else if (boxes.size() == 1) {
             const auto& box = boxes[0];
             const rtxd::Prim &ZH = prims[box[0]], &ZL = prims[box[1]];
             const double lo[3] = {ZH.a, ZH.c, ZL.e}, hi[3] = {ZH.b, ZH.d, ZH.e};
+            rtxd::BvhMap M{};
             for (int i = 0; i < 3; ++i) {
                 const double inv = 1.0 / (hi[i] - lo[i]);
-                for (int j = 0; j < 3; ++j) I.f[3 * i + j] = (float)(S.m[3 * i + j] * inv);
-                I.f[9 + i] = (float)((S.m[9 + i] - lo[i]) * inv);
+                for (int j = 0; j < 3; ++j) M.m[3 * i + j] = (float)(S.m[3 * i + j] * inv);
+                M.m[9 + i] = (float)((S.m[9 + i] - lo[i]) * inv);
             }
-            I.type = rtxd::kBvhItemBox;
-            I.count = 6;
+            I.map = (uint32_t)maps.size();
+            maps.push_back(M);
+            I.type_count = rtxd::kBvhItemBox | (6u << 8);
             for (uint32_t f = 0; f < 6; ++f) push(box[f]);
         } else {
             for (uint32_t p = G.prim_begin; p < G.prim_end; ++p) used[p] = 0;  // a partial box match
-            std::memcpy(I.f, S.m, sizeof I.f);
-            I.type = rtxd::kBvhItemGroup;
-            I.aux = G.prim_begin;
-            I.count = n;
+            rtxd::BvhMap M{};
+            std::memcpy(M.m, S.m, sizeof M.m);
+            I.map = (uint32_t)maps.size();
+            maps.push_back(M);
+            I.type_count = rtxd::kBvhItemGroup | (n << 8);
+            std::memcpy(&I.f[0], &G.prim_begin, sizeof(uint32_t));  // the first primitive, as bits
             for (uint32_t p = G.prim_begin; p < G.prim_end; ++p) push(p);
         }
         out.push_back(I);
@@ -472,6 +478,8 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
         if (!(use_bvh && c == 0))
             while (q < s->n_prims && s->prim_chain[q] == c) ++q;
         for (uint32_t k = p; k < q; ++k) prims[k].group = (uint32_t)groups.size();
+        if (use_bvh && q - p >= (1u << 24))  // a leaf record counts the primitives of a group in 24 bits
+            return fail(RTX_ERR_TOO_LARGE, "more than 2^24 primitives under one transform chain");
         groups.push_back(rtxd::Group{p, q, s->chain_begin[c], s->chain_begin[c + 1]});
         p = q;
     }
@@ -547,13 +555,15 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     std::vector<rtxd::ScanHit> scan_info;
     std::vector<uint32_t> scan_orig;
     if (!use_bvh) build_scan_table(prims, info, groups, steps, scan_groups, scan_recs, scan_info, scan_orig);
-    std::vector<rtxd::BvhNode> nodes;
-    std::vector<rtxd::Group> items;
+    rtxbvh::Tree tree;
+    std::vector<rtxd::BvhNode>& nodes = tree.nodes;
+    std::vector<rtxd::Group>& items = tree.items;  // leaf order, then the items outside the tree
     std::vector<rtxd::BvhFastItem> fast_items;
+    std::vector<rtxd::BvhMap> fast_maps;
     if (use_bvh) {
         std::string err;
-        if (!rtxbvh::build(prims, groups, steps, nodes, items, err)) return fail(RTX_ERR_TOO_LARGE, err);
-        build_bvh_fast_items(prims, info, items, steps, fast_items, scan_info, scan_orig);
+        if (!rtxbvh::build(prims, groups, steps, tree, err)) return fail(RTX_ERR_TOO_LARGE, err);
+        build_bvh_fast_items(prims, info, items, steps, fast_items, fast_maps, scan_info, scan_orig);
     }
 
     RTX_HIP(ctx->prims.upload(prims_padded));
@@ -572,6 +582,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     RTX_HIP(ctx->bvh.upload(nodes));
     RTX_HIP(ctx->bvh_items.upload(items));
     RTX_HIP(ctx->bvh_fast.upload(fast_items));
+    RTX_HIP(ctx->bvh_maps.upload(fast_maps));
 
     rtxd::SceneView& v = ctx->view;
     v.prims = ctx->prims.ptr;
@@ -591,6 +602,11 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     v.bvh = use_bvh ? ctx->bvh.ptr : nullptr;
     v.bvh_items = use_bvh ? ctx->bvh_items.ptr : nullptr;
     v.bvh_fast = use_bvh ? ctx->bvh_fast.ptr : nullptr;
+    v.bvh_maps = use_bvh ? ctx->bvh_maps.ptr : nullptr;
+    std::memcpy(v.bvh_origin, tree.origin, sizeof v.bvh_origin);
+    std::memcpy(v.bvh_scale, tree.scale, sizeof v.bvh_scale);
+    v.n_bvh_big = tree.n_big;
+    v.bvh_big_first = (uint32_t)items.size() - tree.n_big;
     v.n_prims = s->n_prims;
     v.n_groups = (uint32_t)groups.size();
     v.n_steps = s->n_steps;

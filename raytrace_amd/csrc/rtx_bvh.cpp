@@ -110,33 +110,74 @@ struct TmpNode {
     uint32_t left = 0, count = 0;  // count == 0: inner, children left / left+1; else leaf items [left, left+count)
 };
 
-void store_box(float lo[3], float hi[3], const Box& b) {
+// The grid the boxes are stored on: origin + q * scale, q = 0 .. 65535 per axis.
+struct Grid {
+    float origin[3], scale[3];
+};
+
+Grid make_grid(const Box& root) {
+    Grid g;
     for (int a = 0; a < 3; ++a) {
-        // round outwards when narrowing to fp32
-        lo[a] = std::nextafterf((float)b.lo[a], -FLT_MAX);
-        hi[a] = std::nextafterf((float)b.hi[a], FLT_MAX);
+        const double ext = std::max(root.hi[a] - root.lo[a], 1e-30);
+        // two steps of slack at either end for the outward rounding below
+        g.scale[a] = std::nextafterf((float)(ext / 65530.0), FLT_MAX);
+        g.origin[a] = std::nextafterf((float)(root.lo[a] - 2.0 * g.scale[a]), -FLT_MAX);
+    }
+    return g;
+}
+
+// Outward rounding by one whole step beyond floor / ceil: the traversal evaluates
+// origin + q * scale folded into the ray's slab constants in fp32, whose rounding error is
+// orders of magnitude below a grid step (1 / 65530 of the scene's extent).
+void store_box(uint16_t lo[3], uint16_t hi[3], const Box& b, const Grid& g) {
+    for (int a = 0; a < 3; ++a) {
+        const double l = std::floor((b.lo[a] - (double)g.origin[a]) / (double)g.scale[a]) - 1.0;
+        const double h = std::ceil((b.hi[a] - (double)g.origin[a]) / (double)g.scale[a]) + 1.0;
+        lo[a] = (uint16_t)std::min(std::max(l, 0.0), 65535.0);
+        hi[a] = (uint16_t)std::min(std::max(h, 0.0), 65535.0);
     }
 }
 
 }  // namespace
 
 bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,
-           const std::vector<rtxd::Step>& steps, std::vector<rtxd::BvhNode>& out_nodes,
-           std::vector<rtxd::Group>& items, std::string& err) {
+           const std::vector<rtxd::Step>& steps, Tree& out, std::string& err) {
     std::vector<TmpNode> nodes;
+    std::vector<rtxd::BvhNode>& out_nodes = out.nodes;
+    std::vector<rtxd::Group>& items = out.items;
     out_nodes.clear();
-    const uint32_t n = (uint32_t)groups.size();
+    const uint32_t n_all = (uint32_t)groups.size();
     items.clear();
-    if (n == 0) {
+    out.n_big = 0;
+    if (n_all == 0) {
         err = "no groups";
         return false;
     }
-    std::vector<BuildItem> it(n);
-    for (uint32_t g = 0; g < n; ++g) {
+    std::vector<BuildItem> it(n_all);
+    std::vector<double> extent(n_all);
+    for (uint32_t g = 0; g < n_all; ++g) {
         it[g].box = group_box(prims, groups[g], steps);
         it[g].group = g;
         for (int a = 0; a < 3; ++a) it[g].centre[a] = 0.5 * (it[g].box.lo[a] + it[g].box.hi[a]);
+        extent[g] = std::max({it[g].box.hi[0] - it[g].box.lo[0], it[g].box.hi[1] - it[g].box.lo[1],
+                              it[g].box.hi[2] - it[g].box.lo[2]});
     }
+    // Items far larger than the typical one stay out of the tree (at most kMaxBig of them, the
+    // largest first): see Tree.
+    constexpr uint32_t kMaxBig = 8;
+    std::vector<uint32_t> big;
+    if (n_all >= 32) {
+        std::vector<double> sorted = extent;
+        std::nth_element(sorted.begin(), sorted.begin() + n_all / 2, sorted.end());
+        const double limit = 32.0 * sorted[n_all / 2];
+        for (uint32_t g = 0; g < n_all; ++g)
+            if (extent[g] > limit) big.push_back(g);
+        std::sort(big.begin(), big.end(), [&](uint32_t x, uint32_t y) { return extent[x] > extent[y]; });
+        if (big.size() > kMaxBig) big.resize(kMaxBig);
+        std::sort(big.begin(), big.end());
+        for (size_t k = big.size(); k-- > 0;) it.erase(it.begin() + big[k]);
+    }
+    const uint32_t n = (uint32_t)it.size();
     constexpr uint32_t kLeafItems = 2;
     constexpr int kBins = 16;
     nodes.reserve(2 * (size_t)n);
@@ -235,6 +276,13 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
     }
     items.resize(n);
     for (uint32_t k = 0; k < n; ++k) items[k] = groups[it[k].group];
+    for (uint32_t g : big) items.push_back(groups[g]);
+    out.n_big = (uint32_t)big.size();
+    const Grid grid = make_grid(nodes[0].box);
+    for (int a = 0; a < 3; ++a) {
+        out.origin[a] = grid.origin[a];
+        out.scale[a] = grid.scale[a];
+    }
 
     // Convert to two-child nodes.  A child reference is a node index or a tagged leaf.
     std::vector<uint32_t> inner_index(nodes.size(), 0);
@@ -252,9 +300,11 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
     }
     if (nodes[0].count != 0) {
         // a single leaf: root node with one real child and one empty box
+        // (the leaf is then visited twice when the ray meets its box: harmless, a primitive
+        // that already holds the nearest hit does not win against itself)
         rtxd::BvhNode R{};
-        store_box(R.lo0, R.hi0, nodes[0].box);
-        for (int a = 0; a < 3; ++a) { R.lo1[a] = FLT_MAX; R.hi1[a] = -FLT_MAX; }
+        store_box(R.lo0, R.hi0, nodes[0].box, grid);
+        store_box(R.lo1, R.hi1, nodes[0].box, grid);
         R.child0 = ref_of(0);
         R.child1 = R.child0;
         out_nodes.push_back(R);
@@ -266,8 +316,8 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
         if (N.count != 0) continue;
         rtxd::BvhNode& O = out_nodes[inner_index[k]];
         O = rtxd::BvhNode{};
-        store_box(O.lo0, O.hi0, nodes[N.left].box);
-        store_box(O.lo1, O.hi1, nodes[N.left + 1].box);
+        store_box(O.lo0, O.hi0, nodes[N.left].box, grid);
+        store_box(O.lo1, O.hi1, nodes[N.left + 1].box, grid);
         O.child0 = ref_of(N.left);
         O.child1 = ref_of(N.left + 1);
     }

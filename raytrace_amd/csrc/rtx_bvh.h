@@ -17,10 +17,24 @@ namespace rtxbvh {
 // Maximum tree depth the traversal stack supports (see kBvhStack in rtx_core.h).
 constexpr int kMaxDepth = 22;
 
-// nodes[0] is the root (two-child nodes, see rtxd::BvhNode); `items` are the groups in leaf
-// order.  Returns false (and sets err) if the tree cannot be built within kMaxDepth.
+// What the builder hands back.
+//   nodes   two-child nodes with 16-bit boxes on the grid `origin + q * scale` (rtxd::BvhNode),
+//           nodes[0] is the root; every box is rounded outwards by at least one grid step
+//   items   the groups in leaf order, followed by `n_big` groups that are NOT in the tree:
+//           items far larger than the typical one (a ground sphere of radius 1000 under spheres
+//           of radius 0.2, a floor under 100 000 small objects).  Every ray tests them directly;
+//           inside the tree they would overlap everything and, worse, stretch the grid the
+//           boxes are quantised on.
+struct Tree {
+    std::vector<rtxd::BvhNode> nodes;
+    std::vector<rtxd::Group> items;
+    uint32_t n_big = 0;
+    float origin[3] = {0, 0, 0};
+    float scale[3] = {1, 1, 1};
+};
+
+// Returns false (and sets err) if the tree cannot be built within kMaxDepth.
 bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,
-           const std::vector<rtxd::Step>& steps, std::vector<rtxd::BvhNode>& nodes,
-           std::vector<rtxd::Group>& items, std::string& err);
+           const std::vector<rtxd::Step>& steps, Tree& out, std::string& err);
 
 }  // namespace rtxbvh

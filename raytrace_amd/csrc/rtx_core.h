@@ -597,19 +597,45 @@ RTX_DEV bool tie_wins(uint32_t cand, bool cand_is_rect, uint32_t cur, bool cur_i
     return cand < cur;
 }
 
-// Conservative ray / box test (the builder pads the boxes by far more than the rounding of
-// these products); returns the entry distance.  noi = -o * inv, so a plane distance is one
-// fma.  inv must be finite (the caller clamps it): with an infinite one, lo * inv + noi is
-// -inf for a negative lo but NaN for a positive hi, and min / max would then keep the -inf
-// and reject a box the parallel ray runs through.
-RTX_DEV bool slab(const float lo[3], const float hi[3], V3 inv, V3 noi, float t0, float t1, float& t_near) {
-    float tx0 = __builtin_fmaf(lo[0], inv.x, noi.x), tx1 = __builtin_fmaf(hi[0], inv.x, noi.x);
-    float ty0 = __builtin_fmaf(lo[1], inv.y, noi.y), ty1 = __builtin_fmaf(hi[1], inv.y, noi.y);
-    float tz0 = __builtin_fmaf(lo[2], inv.z, noi.z), tz1 = __builtin_fmaf(hi[2], inv.z, noi.z);
+// The nodes' boxes are 16-bit coordinates q on the grid origin + q * scale (rounded outwards
+// by the builder, which also pads the boxes by far more than the rounding of these products).
+// Per ray: t(q) = (origin + q * scale - o) * inv = q * A + B with A = scale * inv and
+// B = origin * inv + noi, noi = -o * inv, so a plane distance is one conversion and one fma.
+// inv must be finite (the caller clamps it): a ray (all but) parallel to a slab is then inside
+// it for every t or for none.
+struct BvhRay {
+    V3 A, B;
+};
+RTX_DEV BvhRay bvh_ray(const SceneView& sc, V3 inv, V3 noi) {
+    BvhRay r;
+    r.A = v3(sc.bvh_scale[0] * inv.x, sc.bvh_scale[1] * inv.y, sc.bvh_scale[2] * inv.z);
+    r.B = v3(__builtin_fmaf(sc.bvh_origin[0], inv.x, noi.x), __builtin_fmaf(sc.bvh_origin[1], inv.y, noi.y),
+             __builtin_fmaf(sc.bvh_origin[2], inv.z, noi.z));
+    return r;
+}
+// One child's box: w0 = lo.x | lo.y << 16, w1 = lo.z | hi.x << 16, w2 = hi.y | hi.z << 16.
+// Conservative; returns the entry distance.
+RTX_DEV bool slab(uint32_t w0, uint32_t w1, uint32_t w2, const BvhRay& r, float t0, float t1, float& t_near) {
+    const float lx = (float)(w0 & 0xffffu), ly = (float)(w0 >> 16), lz = (float)(w1 & 0xffffu);
+    const float hx = (float)(w1 >> 16), hy = (float)(w2 & 0xffffu), hz = (float)(w2 >> 16);
+    float tx0 = __builtin_fmaf(lx, r.A.x, r.B.x), tx1 = __builtin_fmaf(hx, r.A.x, r.B.x);
+    float ty0 = __builtin_fmaf(ly, r.A.y, r.B.y), ty1 = __builtin_fmaf(hy, r.A.y, r.B.y);
+    float tz0 = __builtin_fmaf(lz, r.A.z, r.B.z), tz1 = __builtin_fmaf(hz, r.A.z, r.B.z);
     float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t0));
     float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), t1));
     t_near = tn;
     return tn <= tf;
+}
+// A node as its eight 32-bit words (two 16-byte loads).
+struct NodeWords {
+    uint4 a, b;  // a.xyz: child 0's box, a.w | b.xy: child 1's box, b.z / b.w: the children
+};
+RTX_DEV NodeWords load_node(const SceneView& sc, uint32_t ref) {
+    const uint4* p = reinterpret_cast<const uint4*>(sc.bvh + ref);
+    NodeWords n;
+    n.a = p[0];
+    n.b = p[1];
+    return n;
 }
 
 // Next deferred subtree of this lane, or 0xffffffff when its stack is empty.  An entry that
@@ -627,7 +653,8 @@ RTX_DEV uint32_t pop_ref(uint32_t (*stack)[kCols], uint32_t& sp, uint32_t tid) {
 // fast mode only has to be statistically equal.
 RTX_DEV void fast_leaf_item(const SceneView& sc, const BvhFastItem& I, V3 o, V3 d, V3 inv, V3 noi, float t0,
                             float& closest, uint32_t& best) {
-    if (I.type == kBvhItemSphere) {
+    const uint32_t type = I.type_count & 0xffu;
+    if (type == kBvhItemSphere) {
         // roots of a t^2 + 2 h t + c = 0 with h = oc.d (Sphere.cpp:9-15 with b = 2h)
         const float a = dot(d, d), inv_a = frcp(a);
         const V3 oc = o - v3(I.f[0], I.f[1], I.f[2]);
@@ -639,8 +666,8 @@ RTX_DEV void fast_leaf_item(const SceneView& sc, const BvhFastItem& I, V3 o, V3 
         const bool ok = (D > 0.0f) & (t > t0) & (t < closest);
         closest = ok ? t : closest;
         best = ok ? I.slot : best;
-    } else if (I.type <= kBvhItemRectYZ) {
-        const bool xy = I.type == kBvhItemRectXY, yz = I.type == kBvhItemRectYZ;
+    } else if (type <= kBvhItemRectYZ) {
+        const bool xy = type == kBvhItemRectXY, yz = type == kBvhItemRectYZ;
         // plane coordinate zi, in-plane xi / yi: XY (0,1,2), XZ (0,2,1), YZ (1,2,0)
         const float iz = xy ? inv.z : (yz ? inv.x : inv.y), nz = xy ? noi.z : (yz ? noi.x : noi.y);
         const float ox = yz ? o.y : o.x, dx = yz ? d.y : d.x;
@@ -650,9 +677,10 @@ RTX_DEV void fast_leaf_item(const SceneView& sc, const BvhFastItem& I, V3 o, V3 
         const bool ok = (t >= t0) & (t <= closest) & (x >= I.f[0]) & (x <= I.f[1]) & (y >= I.f[2]) & (y <= I.f[3]);
         closest = ok ? t : closest;
         best = ok ? I.slot : best;
-    } else if (I.type == kBvhItemBox) {
+    } else if (type == kBvhItemBox) {
         // the box is [0,1]^3 in the record's frame: plane distances are noi and inv + noi
-        const float* m = I.f;
+        const BvhMap M = sc.bvh_maps[I.map];
+        const float* m = M.m;
         const V3 ro = v3(m[0] * o.x + m[1] * o.y + m[2] * o.z + m[9], m[3] * o.x + m[4] * o.y + m[5] * o.z + m[10],
                          m[6] * o.x + m[7] * o.y + m[8] * o.z + m[11]);
         const V3 rd = v3(m[0] * d.x + m[1] * d.y + m[2] * d.z, m[3] * d.x + m[4] * d.y + m[5] * d.z,
@@ -679,14 +707,16 @@ RTX_DEV void fast_leaf_item(const SceneView& sc, const BvhFastItem& I, V3 o, V3 
         closest = ok ? t : closest;
         best = ok ? I.slot + face : best;
     } else {  // any other transformed group: its primitives one by one in the group's frame
-        const float* m = I.f;
+        const BvhMap M = sc.bvh_maps[I.map];
+        const float* m = M.m;
+        const uint32_t first = __float_as_uint(I.f[0]), count = I.type_count >> 8;
         const V3 ro = v3(m[0] * o.x + m[1] * o.y + m[2] * o.z + m[9], m[3] * o.x + m[4] * o.y + m[5] * o.z + m[10],
                          m[6] * o.x + m[7] * o.y + m[8] * o.z + m[11]);
         const V3 rd = v3(m[0] * d.x + m[1] * d.y + m[2] * d.z, m[3] * d.x + m[4] * d.y + m[5] * d.z,
                          m[6] * d.x + m[7] * d.y + m[8] * d.z);
         const RayAux aux = make_aux(ro, rd);
-        for (uint32_t k = 0; k < I.count; ++k) {
-            const Prim P = sc.prims[I.aux + k];
+        for (uint32_t k = 0; k < count; ++k) {
+            const Prim P = sc.prims[first + k];
             float t;
             if (prim_test(P, ro, rd, aux, t0, closest, t)) {
                 closest = t;
@@ -713,28 +743,41 @@ RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool w
                       __builtin_amdgcn_fmed3f(frcp(d.z), -kBig, kBig));
     const V3 noi = v3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
     constexpr uint32_t kDone = 0xffffffffu;
+    const BvhRay br = bvh_ray(sc, inv, noi);
     uint32_t ref = 0;  // root node
+    // The items outside the tree first (every ray tests them, the loop is wave-uniform), then the
+    // tree; `big` counts down to the switch.
+    uint32_t big = sc.n_bvh_big;
     for (;;) {
-        // descend to a leaf
-        while (ref != kDone && !(ref & kBvhLeaf)) {
-            const BvhNode N = sc.bvh[ref];
-            float n0, n1;
-            const bool h0 = slab(N.lo0, N.hi0, inv, noi, t0, closest, n0);
-            const bool h1 = slab(N.lo1, N.hi1, inv, noi, t0, closest, n1);
-            if (h0 & h1) {
-                const bool first0 = n0 <= n1;
-                if (sp < (uint32_t)kBvhStack) s_stack[sp][tid] = first0 ? N.child1 : N.child0;
-                ++sp;
-                ref = first0 ? N.child0 : N.child1;
-            } else if (h0 | h1) {
-                ref = h0 ? N.child0 : N.child1;
-            } else {
-                ref = pop_ref(s_stack, sp, tid);
+        uint32_t first, count;
+        if (big != 0u) {
+            --big;
+            first = sc.bvh_big_first + big;
+            count = 1u;
+        } else {
+            // descend to a leaf
+            while (ref != kDone && !(ref & kBvhLeaf)) {
+                const NodeWords N = load_node(sc, ref);
+                float n0, n1;
+                const bool h0 = slab(N.a.x, N.a.y, N.a.z, br, t0, closest, n0);
+                const bool h1 = slab(N.a.w, N.b.x, N.b.y, br, t0, closest, n1);
+                if (h0 & h1) {
+                    const bool first0 = n0 <= n1;
+                    if (sp < (uint32_t)kBvhStack) s_stack[sp][tid] = first0 ? N.b.w : N.b.z;
+                    ++sp;
+                    ref = first0 ? N.b.z : N.b.w;
+                } else if (h0 | h1) {
+                    ref = h0 ? N.b.z : N.b.w;
+                } else {
+                    ref = pop_ref(s_stack, sp, tid);
+                }
             }
+            if (ref == kDone) break;
+            // leaf: items [first, first+count)
+            first = ref & kBvhLeafFirst;
+            count = (ref >> kBvhLeafCountShift) & 15u;
+            ref = pop_ref(s_stack, sp, tid);
         }
-        if (ref == kDone) break;
-        // leaf: items [first, first+count)
-        const uint32_t first = ref & kBvhLeafFirst, count = (ref >> kBvhLeafCountShift) & 15u;
 #if RTX_DET
         for (uint32_t k = 0; k < count; ++k) {
             const Group G = sc.bvh_items[first + k];
@@ -761,7 +804,6 @@ RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool w
 #else
         for (uint32_t k = 0; k < count; ++k) fast_leaf_item(sc, sc.bvh_fast[first + k], o, d, inv, noi, t0, closest, best);
 #endif
-        ref = pop_ref(s_stack, sp, tid);
     }
     if (best == kNone) return false;
 #if RTX_DET
@@ -1444,6 +1486,8 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
     uint32_t ref = kDone, sp = 0, best = kNone;
     float closest = kFltMax;
     V3 inv = v3(0.0f, 0.0f, 0.0f), noi = inv;
+    BvhRay br;
+    br.A = br.B = inv;
     const float fnx = (float)a.width, fny = (float)a.height;
 
     for (;;) {
@@ -1499,10 +1543,15 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 inv = v3(__builtin_amdgcn_fmed3f(frcp(ps.d.x), -kBig, kBig), __builtin_amdgcn_fmed3f(frcp(ps.d.y), -kBig, kBig),
                          __builtin_amdgcn_fmed3f(frcp(ps.d.z), -kBig, kBig));
                 noi = v3(-ps.o.x * inv.x, -ps.o.y * inv.y, -ps.o.z * inv.z);
+                br = bvh_ray(sc, inv, noi);
                 ref = 0u;  // root
                 sp = 0u;
                 closest = kFltMax;
                 best = kNone;
+                // the items outside the tree: every ray tests them (wave-uniform records)
+                for (uint32_t k = 0; k < sc.n_bvh_big; ++k)
+                    fast_leaf_item(sc, load_uniform(sc.bvh_fast, sc.bvh_big_first + k), ps.o, ps.d, inv, noi, kTMin,
+                                   closest, best);
                 phase = kWalk;
             }
         }
@@ -1521,17 +1570,17 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
             const uint32_t n_leaves = (uint32_t)__popcll(__ballot(at_leaf));
             if (nodes == 0ull && n_leaves == 0u) break;
             if (at_node) {
-                const BvhNode N = sc.bvh[ref];
+                const NodeWords N = load_node(sc, ref);
                 float n0, n1;
-                const bool h0 = slab(N.lo0, N.hi0, inv, noi, kTMin, closest, n0);
-                const bool h1 = slab(N.lo1, N.hi1, inv, noi, kTMin, closest, n1);
+                const bool h0 = slab(N.a.x, N.a.y, N.a.z, br, kTMin, closest, n0);
+                const bool h1 = slab(N.a.w, N.b.x, N.b.y, br, kTMin, closest, n1);
                 if (h0 & h1) {
                     const bool first0 = n0 <= n1;
-                    if (sp < (uint32_t)kBvhStack) s_stack[sp][tid] = first0 ? N.child1 : N.child0;
+                    if (sp < (uint32_t)kBvhStack) s_stack[sp][tid] = first0 ? N.b.w : N.b.z;
                     ++sp;
-                    ref = first0 ? N.child0 : N.child1;
+                    ref = first0 ? N.b.z : N.b.w;
                 } else if (h0 | h1) {
-                    ref = h0 ? N.child0 : N.child1;
+                    ref = h0 ? N.b.z : N.b.w;
                 } else {
                     ref = pop_ref(s_stack, sp, tid);
                 }

@@ -121,34 +121,39 @@ constexpr uint32_t kLightsGeneral = 1u;  // SceneView::light_flags: RTX_LIGHTS_G
 constexpr uint32_t kLightsTree = 2u;     // nested lists, chains or XY / YZ rect lights present: tree kernels
 
 // BVH over top-level items (a bare primitive, or one transformed instance such as a Box under
-// Rotate / Translate).  A node holds the boxes of BOTH its children, so one 64-byte fetch
-// decides two subtrees.  A child reference is either the index of another node or, with
-// kBvhLeaf set, a leaf: items [ref & kBvhLeafFirst, + ((ref >> 27) & 15)] of `bvh_items`.
-struct alignas(64) BvhNode {
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
+// Rotate / Translate).  A node holds the boxes of BOTH its children, so one 32-byte fetch (two
+// 16-byte loads per lane) decides two subtrees; traversal is bound by these fetches, not by
+// arithmetic, so the boxes are 16-bit coordinates on a grid over the tree's bounds
+// (world = bvh_origin + q * bvh_scale per axis, rounded outwards when built), decoded inside the
+// slab test's fused multiply-adds.  A child reference is either the index of another node or,
+// with kBvhLeaf set, a leaf: items [ref & kBvhLeafFirst, + ((ref >> 27) & 15)] of `bvh_items`.
+struct alignas(32) BvhNode {
+    uint16_t lo0[3], hi0[3];
+    uint16_t lo1[3], hi1[3];
     uint32_t child0, child1;
-    uint32_t pad[2];
 };
 constexpr uint32_t kBvhLeaf = 0x80000000u;
 constexpr uint32_t kBvhLeafFirst = 0x07ffffffu;
 constexpr uint32_t kBvhLeafCountShift = 27u;
 
-// Fast-mode leaf record, one per BVH item in leaf order, so that a leaf costs one 64-byte
+// Fast-mode leaf record, one per BVH item in leaf order, so that a leaf costs one 32-byte
 // fetch instead of the chain item -> steps -> primitive:
 //   kBvhItemSphere  f = centre xyz, r*r                       (untransformed sphere)
 //   kBvhItemRect*   f = x0 x1 y0 y1 k                         (untransformed rect of that axis)
-//   kBvhItemBox     f = world -> unit-cube affine map (rows of the 3x3, then the offset): a
-//                   complete box under any Translate / Rotate chain; the scaling of the map
-//                   keeps the ray parameter t, so the slab test is against [0,1]^3
-//   kBvhItemGroup   f = world -> group affine map; primitives [aux, aux + count) of `prims`
+//   kBvhItemBox     map = world -> unit-cube affine map (BvhMap, rows of the 3x3, then the
+//                   offset): a complete box under any Translate / Rotate chain; the scaling of
+//                   the map keeps the ray parameter t, so the slab test is against [0,1]^3
+//   kBvhItemGroup   map = world -> group affine map; primitives [first, first + count) of `prims`
 // `slot` is the item's first position in scan_info / scan_orig (box: + face, group: + index).
-struct alignas(64) BvhFastItem {
-    float f[12];
+struct alignas(32) BvhFastItem {
+    float f[5];
     uint32_t slot;
-    uint32_t aux;
-    uint32_t type;
-    uint32_t count;
+    uint32_t type_count;  // type | count << 8
+    uint32_t map;         // box / group: index into BvhMap[]
+    // group only: the first primitive travels in the bits of f[0]
+};
+struct alignas(16) BvhMap {
+    float m[12];
 };
 constexpr uint32_t kBvhItemRectXY = 0u, kBvhItemRectXZ = 1u, kBvhItemRectYZ = 2u;  // = RTX_PRIM_*
 constexpr uint32_t kBvhItemSphere = 3u, kBvhItemBox = 4u, kBvhItemGroup = 5u;
@@ -170,8 +175,12 @@ struct SceneView {
     uint32_t n_scan_groups;
     uint32_t scan_pad_;
     const BvhNode* bvh;        // null: linear scan over groups
-    const Group* bvh_items;    // the groups in leaf order (one load from leaf to primitive range)
+    const Group* bvh_items;    // the groups in leaf order (one load from leaf to primitive range),
+                               // then the n_bvh_big groups outside the tree that every ray tests
     const BvhFastItem* bvh_fast;  // the same items as fast-mode leaf records
+    const BvhMap* bvh_maps;       // affine maps of the box / group records
+    float bvh_origin[3], bvh_scale[3];  // the grid of the nodes' 16-bit boxes
+    uint32_t bvh_big_first, n_bvh_big;
     uint32_t n_prims, n_groups, n_steps, n_materials, n_textures, n_lights, n_bvh_nodes;
     uint32_t light_is_list;
     const LightNode* light_nodes;  // n_light_entries records
