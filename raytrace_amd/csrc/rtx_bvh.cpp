@@ -178,7 +178,10 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
         for (size_t k = big.size(); k-- > 0;) it.erase(it.begin() + big[k]);
     }
     const uint32_t n = (uint32_t)it.size();
-    constexpr uint32_t kLeafItems = 2;
+    // one item per leaf: the leaf code (four record types, each its own branch) is the expensive
+    // part of a traversal step on the GPU; measured 100k-item scene 4.67 (2 items) -> 5.22 Grays/s,
+    // 487-sphere field 21.1 -> 20.6
+    constexpr uint32_t kLeafItems = 1;
     constexpr int kBins = 16;
     nodes.reserve(2 * (size_t)n);
     nodes.emplace_back();
