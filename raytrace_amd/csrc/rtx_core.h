@@ -1431,14 +1431,15 @@ __global__ void __launch_bounds__(RTX_BLOCK, kBvh ? RTX_TRACE_WAVES_BVH : RTX_TR
 // 64 queries before any of them is shaded, here a lane that is done is refilled while the
 // others walk on, and the scattering code runs on a well-filled wave.
 #ifndef RTX_SHADE_BATCH
-#define RTX_SHADE_BATCH 32  // measured 16 .. 56: 32 best on both BVH scenes
+#define RTX_SHADE_BATCH 24  // measured 8 .. 56 (one item per leaf, 32-byte nodes): 16 best on the 100k-item
+                            // scene (5.52 Grays/s), 32 on the 487-sphere field; 24: 5.45 / 20.9
 #endif
 #ifndef RTX_WALK_STEPS
 #define RTX_WALK_STEPS 16   // traversal steps between two looks at the wave's state (1 .. 32 measured)
 #endif
 constexpr uint32_t kShadeBatch = RTX_SHADE_BATCH;
 #ifndef RTX_LEAF_BATCH
-#define RTX_LEAF_BATCH 16
+#define RTX_LEAF_BATCH 8  // measured 4 .. 32
 #endif
 constexpr uint32_t kLeafBatch = RTX_LEAF_BATCH;
 // One wave per block: a block's LDS and wave slots are free as soon as ITS pool is spent (the
