@@ -647,6 +647,7 @@ RTX_DEV uint32_t pop_ref(uint32_t (*stack)[kCols], uint32_t& sp, uint32_t tid) {
     return sp < (uint32_t)kBvhStack ? stack[sp][tid] : kBvhLeaf;
 }
 
+
 #if !RTX_DET
 // One fast-mode leaf record against this lane's ray (inv / noi: the capped reciprocal
 // direction and -o * inv of the traversal).  Ties between equal distances are not ordered:
