@@ -362,3 +362,37 @@ def test_light_tree_arrays_are_validated(gpu_ctx):
     v.light_sampling = 7
     with pytest.raises(api.RtxError):
         gpu_ctx.upload(v, api.RTX_ACCEL_LINEAR)
+
+
+def test_progressive_checkpoint_resumes_bit_identically(gpu_ctx, tmp_path):
+    """A frame resumed from its checkpoint (accumulator + cursor on the sample axis) ends
+    bit-identical to the uninterrupted run: streams are keyed by the absolute sample index."""
+    import torch
+
+    from raytrace_amd.progressive import ProgressiveFrame
+
+    w, h = 64, 36
+    gpu_ctx.upload(api.HostScene("cornell_extra", w, h), api.RTX_ACCEL_LINEAR)
+    for mode in (api.RTX_MODE_FAST, api.RTX_MODE_DETERMINISTIC):
+        whole = ProgressiveFrame(gpu_ctx, w, h, 3, seed=9, mode=mode)
+        for _ in range(4):
+            whole.step()
+        first = ProgressiveFrame(gpu_ctx, w, h, 3, seed=9, mode=mode)
+        first.step()
+        first.step()
+        path = str(tmp_path / f"ckpt{mode}.npz")
+        first.save(path)
+        resumed = ProgressiveFrame(gpu_ctx, w, h, 3, seed=9, mode=mode)
+        assert resumed.load(path) == 6
+        resumed.step()
+        assert resumed.step() == 12
+        torch.cuda.synchronize()
+        assert torch.equal(resumed.frame, whole.frame)
+        assert int(resumed.rays.item()) == int(whole.rays.item())
+        # and it is the frame of one 12-spp launch up to fp32 summation order
+        one, rays = gpu_ctx.render(gpu_ctx.params(w, h, 0, 12, mode=mode, seed=9))
+        assert rays == int(whole.rays.item())
+        assert np.allclose(whole.frame.cpu().numpy(), one, rtol=1e-5, atol=1e-6)
+        other = ProgressiveFrame(gpu_ctx, w, h, 3, seed=10, mode=mode)
+        with pytest.raises(ValueError):
+            other.load(path)

@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--gt-spp", type=int, default=65536)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "progressive"))
     ap.add_argument("--previews", default="1,4,16,64")
+    ap.add_argument("--checkpoint", default="", help="npz file: resume from it if present, rewrite it as the run goes")
+    ap.add_argument("--checkpoint-every", type=int, default=8, help="steps between two checkpoints")
     args = ap.parse_args()
 
     import torch
@@ -57,21 +59,23 @@ def main():
     print(json.dumps({"ground_truth": f"{gw}x{gh}, {args.gt_spp} spp, deterministic, seed 4242",
                       "seconds": time.perf_counter() - t0}), flush=True)
 
+    from raytrace_amd.progressive import ProgressiveFrame
+
     ctx.upload(api.HostScene(args.scene, w, h), api.RTX_ACCEL_AUTO)
-    step = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
-    frame = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
-    rays = torch.zeros(1, dtype=torch.int64, device=dev)
+    prog = ProgressiveFrame(ctx, w, h, args.spp_per_step, seed=0, mode=api.RTX_MODE_FAST)
+    frame, rays = prog.frame, prog.rays
+    first_step = 0
+    if args.checkpoint and os.path.exists(args.checkpoint):
+        first_step = prog.load(args.checkpoint) // args.spp_per_step
+        print(json.dumps({"resumed_from": args.checkpoint, "steps_done": first_step}), flush=True)
     previews = {int(x) for x in args.previews.split(",") if x}
     rows = []
-    for k in range(args.steps):
-        rays.zero_()
+    for k in range(first_step, args.steps):
+        rays_before = int(rays.item())
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(stream)
-        ctx.render_device(ctx.params(w, h, k * args.spp_per_step, args.spp_per_step, mode=api.RTX_MODE_FAST, seed=0),
-                          step.data_ptr(), rays.data_ptr(), stream.cuda_stream)
+        spp = prog.step(stream)
         b.record(stream)
-        frame.add_(step)
-        spp = (k + 1) * args.spp_per_step
         # 4x4 box filter of the running mean (= the quarter-resolution pixel integral), clamped
         # like the ground truth
         small = (frame / spp).reshape(gh, 4, gw, 4, 3).mean(dim=(1, 3))
@@ -79,7 +83,9 @@ def main():
         rmse = float(torch.sqrt(torch.mean((mean - gt) ** 2)).item())
         torch.cuda.synchronize(dev)
         ms = a.elapsed_time(b)
-        r = int(rays.item())
+        r = int(rays.item()) - rays_before
+        if args.checkpoint and ((k + 1) % args.checkpoint_every == 0 or k + 1 == args.steps):
+            prog.save(args.checkpoint)
         row = {"step": k + 1, "spp": spp, "kernel_ms": ms, "grays_per_s": r / ms / 1e6, "rmse": rmse}
         rows.append(row)
         print(json.dumps(row), flush=True)
