@@ -133,6 +133,9 @@ def main() -> int:
     ap.add_argument("--spp-per-step", type=int, default=0)
     ap.add_argument("--mode", default="fast", choices=["fast", "deterministic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true",
+                    help="reduce / resolve on the render stream (no overlap): per-kernel counters then see the "
+                         "trace kernel alone")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -167,7 +170,8 @@ def main() -> int:
     frame_accum = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)  # rank 0: running frame
     rays = torch.zeros(1, dtype=torch.int64, device=dev)
     render_stream = torch.cuda.current_stream(dev)
-    side_stream = torch.cuda.Stream(dev)  # reduce + resolve of step k while step k+1 renders
+    # reduce + resolve of step k while step k+1 renders
+    side_stream = render_stream if args.serial else torch.cuda.Stream(dev)
     ev = {}
 
     total_spp_done = 0
