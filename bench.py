@@ -39,8 +39,8 @@ PEAK_FP32_VALU_TFLOPS = 157.3
 WORKLOADS = {
     # name: (scene, width, height, default spp per step)
     "cornell_1080p": ("cornell", 1920, 1080, 512),
-    "random_field_1080p": ("random_field", 1920, 1080, 64),
-    "bvh_stress_1080p": ("bvh_stress", 1920, 1080, 16),
+    "random_field_1080p": ("random_field", 1920, 1080, 256),  # 4 steps = the 1024-spp frame
+    "bvh_stress_1080p": ("bvh_stress", 1920, 1080, 128),      # 8 GPUs x 1 step = the 1024-spp frame
     "cornell_extra_4k": ("cornell_extra", 3840, 2160, 256),
     "small_400x225": ("small", 400, 225, 100),
 }

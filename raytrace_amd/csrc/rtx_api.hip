@@ -160,6 +160,15 @@ int check_scene(const RtxScene* s) {
             return fail(RTX_ERR_INVALID_ARGUMENT, "light_chain out of range");
         }
     }
+    {   // nesting depth of the light lists (children lie behind their list, so one forward pass)
+        std::vector<uint32_t> depth(n_entries, 0u);
+        for (uint32_t l = 0; l < n_entries; ++l) {
+            if (s->light_kind[l] != RTX_LIGHT_LIST) continue;
+            if (depth[l] >= 63u) return fail(RTX_ERR_UNSUPPORTED, "light lists nested deeper than 64 levels");
+            for (uint32_t k = 0; k < s->light_count[l]; ++k)
+                depth[s->light_first[l] + k] = std::max(depth[s->light_first[l] + k], depth[l] + 1u);
+        }
+    }
     if (!s->light_is_list && s->n_lights != 1)
         return fail(RTX_ERR_INVALID_ARGUMENT,
                     "a bare (non-list) light shape must have exactly one entry (no light at all: n_lights = 0 "

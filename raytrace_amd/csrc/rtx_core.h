@@ -1089,7 +1089,7 @@ RTX_DEV V3 sample_direction_tree(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
             if (index >= sc.n_lights) index = sc.n_lights - 1;
         }
         Light E = sc.lights[index];  // per lane
-        for (int level = 0; level < 16 && E.kind == RTX_LIGHT_LIST; ++level) {  // a nested list picks again
+        for (int level = 0; level < 64 && E.kind == RTX_LIGHT_LIST; ++level) {  // a nested list picks again (the upload bounds the nesting)
             const LightNode L = sc.light_nodes[index];
             float r = rng_nextf(&rng);
             uint32_t k = (uint32_t)(r * (float)L.count);
