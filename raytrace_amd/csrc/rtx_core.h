@@ -1068,12 +1068,20 @@ RTX_DEV float light_pdf_leaf(const Light& E, V3 o, V3 v, bool general) {
 RTX_DEV float light_pdf_tree(const SceneView& sc, V3 o, V3 v) {
     const bool general = (sc.light_flags & kLightsGeneral) != 0u;
     float sum = 0.0f;
+    // consecutive leaves under the same chain (the six faces of a box) share the transformed query
+    uint32_t cur_begin = 0u, cur_end = 0u;
+    V3 ol = o, vl = v;
     for (uint32_t e = 0; e < sc.n_light_entries; ++e) {
         const Light E = load_uniform(sc.lights, e);
         if (E.kind >= RTX_LIGHT_OTHER) continue;  // no density of its own (Shape.h:8) / a list
         const LightNode N = load_uniform(sc.light_nodes, e);
-        V3 ol = o, vl = v;
-        enter_group<true>(sc, N.step_begin, N.step_end, ol, vl);
+        if (N.step_begin != cur_begin || N.step_end != cur_end) {  // wave-uniform
+            cur_begin = N.step_begin;
+            cur_end = N.step_end;
+            ol = o;
+            vl = v;
+            enter_group<true>(sc, cur_begin, cur_end, ol, vl);
+        }
         sum = sum + N.weight * light_pdf_leaf(E, ol, vl, general);
     }
     return sum;
