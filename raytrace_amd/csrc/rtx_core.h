@@ -1245,6 +1245,54 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
         ps.depth += 1;
         return false;
     }
+#if !RTX_DET
+    {   // Metal (Metal.cpp:9-17) and Dielectric (Dielectric.cpp:7-45) in one pass: both mirror the
+        // incoming direction about the normal - Metal the normalised one, Dielectric the raw one -
+        // so the few lanes of either kind share that part instead of running two separate blocks.
+        const bool metal = mat_kind == RTX_MAT_METAL;
+        const float dn = dot(ps.d, rec.n);
+        const float inv_len = finvsqrt(dot(ps.d, ps.d));
+        const float s = metal ? inv_len : 1.0f;
+        V3 reflected = ps.d * s - rec.n * ((2.0f * dn) * s);  // reflect, Util.h:56-58
+        V3 dir = reflected;
+        if (metal) {
+            if (rec.param != 0.0f) {  // a perfect mirror ignores the fuzz vector
+                V3 q;
+                do {  // random_in_unit_sphere, Util.h:32-38
+                    float rz = rng_nextf(&ps.rng);
+                    float ry = rng_nextf(&ps.rng);
+                    float rx = rng_nextf(&ps.rng);
+                    q = v3(rx, ry, rz) * 2.0f - v3(1.0f, 1.0f, 1.0f);
+                } while (length_sqr(q) >= 1.0f);
+                reflected = reflected + q * rec.param;
+                dir = reflected;
+            }
+            if (!(dot(reflected, rec.n) > 0.0f)) return true;
+            ps.T = vmul(surface_color(sc, rec), ps.T);  // Scene.cpp:110
+        } else {
+            const float ri = rec.param;
+            const bool inside = dn > 0.0f;
+            const V3 outward = inside ? -rec.n : rec.n;
+            const float ni_over_nt = inside ? ri : frcp(ri);
+            const float dt = __builtin_fabsf(dn) * inv_len;          // dot(normalize(-d), outward)
+            const float cosine = inside ? ri * dt : dt;               // Dielectric.cpp:19,24
+            const float D = 1.0f - (ni_over_nt * ni_over_nt) * (1.0f - dt * dt);  // refract, Util.h:60-71
+            float reflect_prob = 1.0f;
+            V3 refracted = v3(0.0f, 0.0f, 0.0f);
+            if (D > 0.0f) {
+                const V3 uv = ps.d * (-inv_len);
+                refracted = (uv - outward * dt) * (-ni_over_nt) - outward * fsqrt(D);
+                reflect_prob = schlick(cosine, ri);
+            }
+            if (!(rng_nextf(&ps.rng) < reflect_prob)) dir = refracted;
+            // albedo is (1,1,1): the weight is unchanged
+        }
+        ps.o = rec.p;
+        ps.d = dir;
+        ps.depth += 1;
+        return false;
+    }
+#endif
     if (mat_kind == RTX_MAT_METAL) {  // Metal.cpp:9-17
         V3 reflected = reflect(normalize(ps.d), rec.n);
 #if !RTX_DET
