@@ -24,9 +24,13 @@ def main():
     print(f"# rocprofv3 summary of {root}")
     stats = glob.glob(os.path.join(root, "stats", "*.db"))
     log = os.path.join(root, "stats.log")
+    bench_line = None
     if os.path.exists(log):
         for line in open(log):
             if line.startswith("{"):
+                import json
+
+                bench_line = json.loads(line)
                 print("\n## bench.py line of the profiled run (rocprofv3 --kernel-trace --stats)\n" + line.strip())
     if stats:
         print("\n## kernel trace stats (all dispatches of the run, warm-up included)")
@@ -35,9 +39,16 @@ def main():
             print(f"{name[:90]:90s} {calls:6d} {total:14.1f} {avg:12.1f} {pct:7.2f}")
         print("\n## per-dispatch durations of the path-trace kernel")
         print(f"{'dispatch':>8s} {'duration_us':>12s} {'grid':>10s} {'wg':>5s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'lds':>6s} {'scratch':>8s}")
+        durations = []
         for r in rows(stats[0], "select dispatch_id, duration, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size "
                                 "from kernels where name like '%_mode::%' order by start"):
             print(f"{r[0]:8d} {r[1] / 1e3:12.1f} {r[2]:10d} {r[3]:5d} {r[4]:5d} {r[5]:5d} {r[6]:5d} {r[7]:6d} {r[8]:8d}")
+            durations.append(r[1] / 1e3)
+        if bench_line and len(durations) >= bench_line["steps"]:
+            timed = durations[-bench_line["steps"]:]
+            print(f"average of the {len(timed)} timed dispatches (the {bench_line['warmup']} warm-up dispatch(es) before them "
+                  f"excluded): {sum(timed) / len(timed):.1f} us; bench.py's HIP events in the same run: "
+                  f"{bench_line['roofline']['kernel_ms_avg'] * 1e3:.1f} us")
     counters = {}
     meta = None
     for db in sorted(glob.glob(os.path.join(root, "pmc*", "*.db"))):
