@@ -380,7 +380,7 @@ RTX_DEV void finish_hit(const SceneView& sc, uint32_t prim, float t, V3 o, V3 d,
 // Deterministic mode: list order, one generic loop (the order decides ties and the fate of
 // NaN candidates, both of which must come out as in the reference).  The next record is
 // requested before the current one is tested.
-RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool want_uv, HitRec& rec) {
+RTX_DEV bool query_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, float& t_hit, uint32_t& prim_hit) {
     float closest = t1;
     uint32_t best = kNone;
     for (uint32_t g = 0; g < sc.n_groups; ++g) {
@@ -399,9 +399,9 @@ RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, boo
             cur = nxt;
         }
     }
-    if (best == kNone) return false;
-    finish_hit(sc, best, closest, o, d, want_uv, rec);
-    return true;
+    t_hit = closest;
+    prim_hit = best;
+    return best != kNone;
 }
 RTX_DEV uint32_t original_prim(const SceneView&, uint32_t prim, bool) { return prim; }
 #else
@@ -526,7 +526,7 @@ RTX_DEV void scan_boxes(const SceneView& sc, uint32_t& pos, uint32_t count, V3 r
     }
 }
 
-RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool want_uv, HitRec& rec) {
+RTX_DEV bool query_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, float& t_hit, uint32_t& prim_hit) {
     float closest = t1;
     uint32_t best = kNone;
     for (uint32_t g = 0; g < sc.n_scan_groups; ++g) {
@@ -567,10 +567,9 @@ RTX_DEV bool hit_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, boo
         }
         if (G.n_box) scan_boxes(sc, pos, G.n_box, ro, aux, t0, closest, best);
     }
-    if (best == kNone) return false;
-
-    finish_scan_hit<false>(sc, best, closest, o, d, want_uv, rec);
-    return true;
+    t_hit = closest;
+    prim_hit = best;
+    return best != kNone;
 }
 // The fast linear scan reports positions of the bucketed table.
 RTX_DEV uint32_t original_prim(const SceneView& sc, uint32_t prim, bool) { return sc.scan_orig[prim]; }
@@ -731,7 +730,7 @@ RTX_DEV void fast_leaf_item(const SceneView& sc, const BvhFastItem& I, V3 o, V3 
 // Traversal: each lane descends until it holds a leaf (nearer child first, the other one
 // deferred on its stack), then the lanes of the wave test their leaves together.  The stack
 // lives in LDS, one column per thread (entry e of thread t at [e][t]: conflict-free).
-RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool want_uv, HitRec& rec) {
+RTX_DEV bool query_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, float& t_hit, uint32_t& prim_hit) {
     __shared__ uint32_t s_stack[kBvhStack][256];  // hit_kernel runs 256 threads; trace blocks use a prefix
     const uint32_t tid = threadIdx.x;
     uint32_t sp = 0;
@@ -806,20 +805,35 @@ RTX_DEV bool hit_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, bool w
         for (uint32_t k = 0; k < count; ++k) fast_leaf_item(sc, sc.bvh_fast[first + k], o, d, inv, noi, t0, closest, best);
 #endif
     }
-    if (best == kNone) return false;
-#if RTX_DET
-    finish_hit(sc, best, closest, o, d, want_uv, rec);
-#else
     (void)best_is_rect;
-    finish_scan_hit<true>(sc, best, closest, o, d, want_uv, rec);
-#endif
-    return true;
+    t_hit = closest;
+    prim_hit = best;
+    return best != kNone;
 }
 
+// The nearest-hit query proper (winner and distance) and, apart from it, the completion of the
+// winner's record: callers that branch on the outcome complete the record inside the branch that
+// uses it, so that it is not live on the path of a miss.
+template <bool kBvh>
+RTX_DEV bool scene_query(const SceneView& sc, V3 o, V3 d, float t0, float t1, float& t_hit, uint32_t& prim_hit) {
+    if (kBvh) return query_bvh(sc, o, d, t0, t1, t_hit, prim_hit);
+    return query_linear(sc, o, d, t0, t1, t_hit, prim_hit);
+}
+template <bool kBvh>
+RTX_DEV void scene_finish(const SceneView& sc, uint32_t prim_hit, float t_hit, V3 o, V3 d, bool want_uv, HitRec& rec) {
+#if RTX_DET
+    finish_hit(sc, prim_hit, t_hit, o, d, want_uv, rec);
+#else
+    finish_scan_hit<kBvh>(sc, prim_hit, t_hit, o, d, want_uv, rec);
+#endif
+}
 template <bool kBvh>
 RTX_DEV bool scene_hit(const SceneView& sc, V3 o, V3 d, float t0, float t1, HitRec& rec, bool want_uv = false) {
-    if (kBvh) return hit_bvh(sc, o, d, t0, t1, want_uv, rec);
-    return hit_linear(sc, o, d, t0, t1, want_uv, rec);
+    float t_hit;
+    uint32_t prim_hit;
+    if (!scene_query<kBvh>(sc, o, d, t0, t1, t_hit, prim_hit)) return false;
+    scene_finish<kBvh>(sc, prim_hit, t_hit, o, d, want_uv, rec);
+    return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -1430,11 +1444,22 @@ __global__ void __launch_bounds__(RTX_BLOCK, kBvh ? RTX_TRACE_WAVES_BVH : RTX_TR
             continue;  // only slots outside the image were drawn (ragged edge tile)
         }
         if (active) {
-            HitRec rec;
-            bool hit = scene_hit<kBvh>(sc, ps.o, ps.d, kTMin, kFltMax, rec);
+            float t_hit;
+            uint32_t prim_hit;
+            const bool hit = scene_query<kBvh>(sc, ps.o, ps.d, kTMin, kFltMax, t_hit, prim_hit);
             ++segs;
             V3 L;
-            if (shade<kLightTree>(sc, a.max_depth, hit, rec, ps, L)) {
+            bool ended;
+            if (hit) {  // the winner's record lives inside this branch only
+                HitRec rec;
+                scene_finish<kBvh>(sc, prim_hit, t_hit, ps.o, ps.d, false, rec);
+                ended = shade<kLightTree>(sc, a.max_depth, true, rec, ps, L);
+            } else {
+                HitRec none;
+                none.bits = 0u;
+                ended = shade<kLightTree>(sc, a.max_depth, false, none, ps, L);
+            }
+            if (ended) {
                 const uint32_t slot = item & pix_mask;
                 atomicAdd(&s_acc[wave][0][slot], L.x);  // Scene.cpp:148
                 atomicAdd(&s_acc[wave][1][slot], L.y);
