@@ -1443,7 +1443,12 @@ __global__ void __launch_bounds__(RTX_BLOCK, kBvh ? RTX_TRACE_WAVES_BVH : RTX_TR
             if (next >= total) break;
             continue;  // only slots outside the image were drawn (ragged edge tile)
         }
-        if (active) {
+        // Linear scan: no branch around the body.  A lane without an item (only while the pool
+        // drains, or on a ragged edge tile) follows whatever ray it holds and its results are
+        // thrown away; what that costs is nothing the wave would not execute anyway, and the
+        // path state is then carried round the loop without a copy in and out of a conditional
+        // region.  BVH: the traversal is per lane, an idle lane stays out of it.
+        if (kBvh ? active : true) {
             float t_hit;
             uint32_t prim_hit;
             const bool hit = scene_query<kBvh>(sc, ps.o, ps.d, kTMin, kFltMax, t_hit, prim_hit);
@@ -1459,7 +1464,7 @@ __global__ void __launch_bounds__(RTX_BLOCK, kBvh ? RTX_TRACE_WAVES_BVH : RTX_TR
                 none.bits = 0u;
                 ended = shade<kLightTree>(sc, a.max_depth, false, none, ps, L);
             }
-            if (ended) {
+            if (ended && active) {
                 const uint32_t slot = item & pix_mask;
                 atomicAdd(&s_acc[wave][0][slot], L.x);  // Scene.cpp:148
                 atomicAdd(&s_acc[wave][1][slot], L.y);
