@@ -1586,12 +1586,19 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
         const uint32_t waiting = n_done + (pool_left ? (uint32_t)__popcll(idle) : 0u);
         if (waiting != 0u && (walking == 0ull || waiting >= kShadeBatch)) {
             if (phase == kDoneWalk) {  // Scene::color for the finished query
-                HitRec rec;
-                const bool hit = best != kNone;
-                if (hit) finish_scan_hit<true>(sc, best, closest, ps.o, ps.d, false, rec);
                 ++segs;
                 V3 L;
-                if (shade<kLightTree>(sc, a.max_depth, hit, rec, ps, L)) {
+                bool ended;
+                if (best != kNone) {  // the winner's record lives inside this branch only
+                    HitRec rec;
+                    finish_scan_hit<true>(sc, best, closest, ps.o, ps.d, false, rec);
+                    ended = shade<kLightTree>(sc, a.max_depth, true, rec, ps, L);
+                } else {
+                    HitRec none;
+                    none.bits = 0u;
+                    ended = shade<kLightTree>(sc, a.max_depth, false, none, ps, L);
+                }
+                if (ended) {
                     const uint32_t slot = item & pix_mask;
                     atomicAdd(&s_acc[wave][0][slot], L.x);  // Scene.cpp:148
                     atomicAdd(&s_acc[wave][1][slot], L.y);
