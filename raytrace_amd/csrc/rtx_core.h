@@ -144,12 +144,16 @@ RTX_DEV float rng_nextf(RtxRng* r) { return rtx_rng_nextf(r); }
 // conversion per draw, six hashes per sample).  Same structure - a 32-bit LCG per (pixel,
 // absolute sample index, seed) whose odd increment selects the stream - but keyed with two
 // hashes and read out as the top 23 bits of the state placed in the mantissa of [1, 2).
-RTX_DEV void rng_init(RtxRng* r, uint32_t pixel, uint32_t sample, uint64_t seed) {
+RTX_DEV uint32_t rng_pixel_key(uint32_t pixel, uint64_t seed) {
     const uint32_t k = rtx_hash32((uint32_t)seed ^ rtx_hash32((uint32_t)(seed >> 32) ^ 0x9e3779b9u));  // wave-uniform
-    const uint32_t a = rtx_hash32(pixel ^ k);
-    const uint32_t b = rtx_hash32(sample ^ a);
-    r->state = b;
-    r->inc = (a << 1) | 1u;
+    return rtx_hash32(pixel ^ k);
+}
+RTX_DEV void rng_init_keyed(RtxRng* r, uint32_t pixel_key, uint32_t sample) {
+    r->state = rtx_hash32(sample ^ pixel_key);
+    r->inc = (pixel_key << 1) | 1u;
+}
+RTX_DEV void rng_init(RtxRng* r, uint32_t pixel, uint32_t sample, uint64_t seed) {
+    rng_init_keyed(r, rng_pixel_key(pixel, seed), sample);
 }
 RTX_DEV float rng_nextf(RtxRng* r) {
     const uint32_t s = r->state * 747796405u + r->inc;
@@ -1407,6 +1411,20 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
     s_acc[wave][0][lane] = 0.0f;
     s_acc[wave][1][lane] = 0.0f;
     s_acc[wave][2][lane] = 0.0f;
+#if !RTX_DET
+    // What a new item needs of its pixel - the stream key, the coordinates as floats, whether the
+    // slot lies inside the image - is the same for all the samples of the pixel: lane l works it
+    // out once for slot l, and starting an item costs one 16-byte LDS read instead of a hash, an
+    // integer multiply-add and two conversions.
+    __shared__ uint4 s_slot[RTX_BLOCK / 64][64];
+    {
+        const uint32_t sx = lane & (tile_w - 1u), sy = lane >> twl;
+        const uint32_t i = x0 + sx, j = y0 + sy;
+        const bool inside = lane <= pix_mask && sx < tw && sy < th;
+        s_slot[wave][lane] = make_uint4(rng_pixel_key(j * a.width + i, a.seed), __float_as_uint((float)i),
+                                        __float_as_uint((float)j), inside ? 1u : 0u);
+    }
+#endif
 
     const uint32_t total = a.spp_count << pixl;  // items of this wave's pool
     uint32_t next = 0;                         // wave-uniform pool cursor
@@ -1428,13 +1446,22 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
             next += (uint32_t)__popcll(want);
             if (!active && mine < total) {
                 const uint32_t slot = mine & pix_mask;
+#if RTX_DET
                 const uint32_t sx = slot & (tile_w - 1u), sy = slot >> twl;
                 if (sx < tw && sy < th) {
                     item = mine;
                     const uint32_t i = x0 + sx, j = y0 + sy;
                     rng_init(&ps.rng, j * a.width + i, a.spp_begin + (mine >> pixl), a.seed);
-                    float u = fdiv((float)i + rng_nextf(&ps.rng), fnx);  // Scene.cpp:145-146
-                    float v = fdiv((float)j + rng_nextf(&ps.rng), fny);
+                    const float fi = (float)i, fj = (float)j;
+#else
+                const uint4 slot_info = s_slot[wave][slot];
+                if (slot_info.w != 0u) {
+                    item = mine;
+                    rng_init_keyed(&ps.rng, slot_info.x, a.spp_begin + (mine >> pixl));
+                    const float fi = __uint_as_float(slot_info.y), fj = __uint_as_float(slot_info.z);
+#endif
+                    float u = fdiv(fi + rng_nextf(&ps.rng), fnx);  // Scene.cpp:145-146
+                    float v = fdiv(fj + rng_nextf(&ps.rng), fny);
                     // Camera::getRay, Camera.h:24-26
                     ps.o = v3(sc.cam_origin);
                     ps.d = ((v3(sc.cam_ll) + v3(sc.cam_u) * u) + v3(sc.cam_v) * v) - ps.o;
