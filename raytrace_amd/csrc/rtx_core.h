@@ -1417,12 +1417,18 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
     // out once for slot l, and starting an item costs one 16-byte LDS read instead of a hash, an
     // integer multiply-add and two conversions.
     __shared__ uint4 s_slot[RTX_BLOCK / 64][64];
+    const float inv_nx = frcp((float)a.width), inv_ny = frcp((float)a.height);
     {
         const uint32_t sx = lane & (tile_w - 1u), sy = lane >> twl;
         const uint32_t i = x0 + sx, j = y0 + sy;
         const bool inside = lane <= pix_mask && sx < tw && sy < th;
-        s_slot[wave][lane] = make_uint4(rng_pixel_key(j * a.width + i, a.seed), __float_as_uint((float)i),
-                                        __float_as_uint((float)j), inside ? 1u : 0u);
+        // direction of the ray through the pixel's lower left corner (Camera::getRay, Camera.h:24-26);
+        // a sample adds its jitter along the two image axes
+        const float u0 = (float)i * inv_nx, v0 = (float)j * inv_ny;
+        const V3 corner = ((v3(sc.cam_ll) - v3(sc.cam_origin)) + v3(sc.cam_u) * u0) + v3(sc.cam_v) * v0;
+        const uint32_t key = rng_pixel_key(j * a.width + i, a.seed);
+        s_slot[wave][lane] = make_uint4(inside ? (key != 0u ? key : 1u) : 0u, __float_as_uint(corner.x),
+                                        __float_as_uint(corner.y), __float_as_uint(corner.z));
     }
 #endif
 
@@ -1435,7 +1441,9 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
     ps.depth = 0;
     ps.rng.state = 0;
     ps.rng.inc = 1;
+#if RTX_DET
     const float fnx = (float)a.width, fny = (float)a.height;
+#endif
 
     for (;;) {
         const unsigned long long want = __ballot(!active);
@@ -1455,16 +1463,29 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
                     const float fi = (float)i, fj = (float)j;
 #else
                 const uint4 slot_info = s_slot[wave][slot];
-                if (slot_info.w != 0u) {
+                if (slot_info.x != 0u) {  // 0: the slot lies outside the image
                     item = mine;
                     rng_init_keyed(&ps.rng, slot_info.x, a.spp_begin + (mine >> pixl));
-                    const float fi = __uint_as_float(slot_info.y), fj = __uint_as_float(slot_info.z);
+                    const float du = rng_nextf(&ps.rng) * inv_nx;  // Scene.cpp:145-146: u first, then v
+                    const float dv = rng_nextf(&ps.rng) * inv_ny;
+                    ps.o = v3(sc.cam_origin);
+                    ps.d = (v3(__uint_as_float(slot_info.y), __uint_as_float(slot_info.z), __uint_as_float(slot_info.w)) +
+                            v3(sc.cam_u) * du) + v3(sc.cam_v) * dv;
+                    // The reference forms the direction as (lower-left + ...) - origin (Camera.h:24-26),
+                    // i.e. it rounds the point on the image plane in WORLD coordinates before it
+                    // subtracts the origin, which puts the directions on a grid of one ulp of those
+                    // coordinates.  That grid is visible in the statistics (Cornell box: 0.11 % fewer
+                    // rays per sample, 0.15 % more radiance than with exact directions), so it is kept:
+                    // round-trip through the world-space point.
+                    ps.d = (ps.o + ps.d) - ps.o;
 #endif
+#if RTX_DET
                     float u = fdiv(fi + rng_nextf(&ps.rng), fnx);  // Scene.cpp:145-146
                     float v = fdiv(fj + rng_nextf(&ps.rng), fny);
                     // Camera::getRay, Camera.h:24-26
                     ps.o = v3(sc.cam_origin);
                     ps.d = ((v3(sc.cam_ll) + v3(sc.cam_u) * u) + v3(sc.cam_v) * v) - ps.o;
+#endif
                     ps.T = v3(1.0f, 1.0f, 1.0f);
                     ps.depth = 0;
                     segs = 0;
