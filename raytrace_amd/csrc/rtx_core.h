@@ -689,20 +689,12 @@ RTX_DEV void fast_leaf_item(const SceneView& sc, const BvhFastItem& I, V3 o, V3 
                          __builtin_amdgcn_fmed3f(frcp(rd.z), -kBig, kBig));
         const float lx = -ro.x * li.x, ly = -ro.y * li.y, lz = -ro.z * li.z;
         const float hx = lx + li.x, hy = ly + li.y, hz = lz + li.z;
-        const bool px = lx < hx, py = ly < hy, pz = lz < hz;  // travelling towards + along the axis
-        const float nx = px ? lx : hx, fx = px ? hx : lx;
-        const float ny = py ? ly : hy, fy = py ? hy : ly;
-        const float nz = pz ? lz : hz, fz = pz ? hz : lz;
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
-        const float tf = __builtin_fminf(__builtin_fminf(fx, fy), fz);
-        const bool enter = tn >= t0;
-        const float t = enter ? tn : tf;
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx, hx), __builtin_fminf(ly, hy)), __builtin_fminf(lz, hz));
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx, hx), __builtin_fmaxf(ly, hy)), __builtin_fmaxf(lz, hz));
+        const float t = tn >= t0 ? tn : tf;
         const bool ok = (tn <= tf) & (t >= t0) & (t <= closest);
-        const float cx = enter ? nx : fx, cy = enter ? ny : fy;
-        const bool ax = cx == t, ay = cy == t;
-        uint32_t face = ax ? 4u : (ay ? 2u : 0u);
-        const bool towards_plus = ax ? px : (ay ? py : pz);
-        face += (enter == towards_plus) ? 1u : 0u;
+        // the face is the plane whose distance t is (slot order +z -z +y -y +x -x)
+        const uint32_t face = t == lx ? 5u : (t == hx ? 4u : (t == ly ? 3u : (t == hy ? 2u : (t == lz ? 1u : 0u))));
         closest = ok ? t : closest;
         best = ok ? I.slot + face : best;
     } else {  // any other transformed group: its primitives one by one in the group's frame
