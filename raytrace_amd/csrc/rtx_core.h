@@ -558,8 +558,10 @@ RTX_DEV bool query_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, f
                 float tb = (-h + root) * inv_a;
                 // ta <= tb: the near root if it lies beyond t0, else the far one; a near root
                 // at or beyond `closest` rules the far one out too (Sphere.cpp:14-31)
+                // (a negative discriminant makes both roots NaN and every comparison false; with
+                // ta <= tb, "the chosen root lies beyond t0" is "tb lies beyond t0")
                 float t = ta > t0 ? ta : tb;
-                bool ok = (D > 0.0f) & (t > t0) & (t < closest);
+                bool ok = (tb > t0) & (t < closest);
                 closest = ok ? t : closest;
                 best = ok ? pos : best;
             }
