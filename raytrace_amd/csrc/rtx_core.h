@@ -1192,6 +1192,16 @@ struct PathState {
     RtxRng rng;
 };
 
+// On the branches that end a path the state is left alone.  The empty statement below redefines
+// every field IN PLACE (operands tied to themselves), which keeps the register allocator from
+// giving the state after shade() other registers than the state before it - and from copying the
+// one into the other on every path-ending branch and back at the end of the loop.
+RTX_DEV bool pin(PathState& ps) {
+    asm("" : "+v"(ps.o.x), "+v"(ps.o.y), "+v"(ps.o.z), "+v"(ps.d.x), "+v"(ps.d.y), "+v"(ps.d.z), "+v"(ps.T.x), "+v"(ps.T.y),
+             "+v"(ps.T.z), "+v"(ps.depth), "+v"(ps.rng.state));
+    return true;
+}
+
 template <bool kLightTree>
 RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitRec& rec, PathState& ps,
                    V3& L) {
@@ -1204,18 +1214,18 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
             bg = white + (v3(0.5f, 0.7f, 1.0f) - white) * t;  // lerp, vec_aos.h:92-95
         }
         L = vmul(ps.T, bg);
-        return true;
+        return pin(ps);
     }
     const uint32_t mat_kind = rec_mat_kind(rec);
     if (mat_kind == RTX_MAT_DIFFUSE_LIGHT) {  // DiffuseLight.h:17-28: emits on the front face, never scatters
         V3 e = v3(0.0f, 0.0f, 0.0f);
         if (dot(rec.n, ps.d) < 0.0f) e = surface_color(sc, rec);
         L = vmul(ps.T, e);
-        return true;
+        return pin(ps);
     }
     // the other materials emit nothing (Material.h:10)
     L = v3(0.0f, 0.0f, 0.0f);
-    if (ps.depth >= max_depth) return true;  // Scene.cpp:108
+    if (ps.depth >= max_depth) return pin(ps);  // Scene.cpp:108
 
     if (mat_kind == RTX_MAT_LAMBERTIAN) {
         V3 albedo = surface_color(sc, rec);  // Lambertian.cpp:17
@@ -1228,7 +1238,7 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
             const float pdf1 = (cosine > 0.0f ? cosine : 0.0f) * (1.0f / kPi);  // = the scattering pdf
             const float pdf_value =
                 sc.n_lights != 0u ? 0.5f * light_pdf_fast(sc, rec.p, dir, len2, inv_len) + 0.5f * pdf1 : pdf1;
-            if (!(pdf_value > 0.0f)) return true;
+            if (!(pdf_value > 0.0f)) return pin(ps);
             ps.T = vmul(albedo, ps.T) * (pdf1 * frcp(pdf_value));
             ps.o = rec.p;
             ps.d = dir;
@@ -1242,7 +1252,7 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
         float pdf_value = pdf1;  // no light shape: srec.pdf alone
         if (sc.n_lights != 0u)
             pdf_value = 0.5f * (kLightTree ? light_pdf_tree(sc, rec.p, dir) : light_pdf(sc, rec.p, dir)) + 0.5f * pdf1;
-        if (!(pdf_value > 0.0f)) return true;  // Scene.cpp:117,122-124
+        if (!(pdf_value > 0.0f)) return pin(ps);  // Scene.cpp:117,122-124
         // Lambertian::scattering_pdf, Lambertian.cpp:23-25: std::max(cos, 0) / PI
         float c0 = cosine < 0.0f ? 0.0f : cosine;
         float spdf = fdiv(c0, kPi);
@@ -1274,7 +1284,7 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
                 reflected = reflected + q * rec.param;
                 dir = reflected;
             }
-            if (!(dot(reflected, rec.n) > 0.0f)) return true;
+            if (!(dot(reflected, rec.n) > 0.0f)) return pin(ps);
             ps.T = vmul(surface_color(sc, rec), ps.T);  // Scene.cpp:110
         } else {
             const float ri = rec.param;
@@ -1320,7 +1330,7 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
             reflected = reflected + q * rec.param;
         }
         V3 albedo = surface_color(sc, rec);
-        if (!(dot(reflected, rec.n) > 0.0f)) return true;
+        if (!(dot(reflected, rec.n) > 0.0f)) return pin(ps);
         ps.T = vmul(albedo, ps.T);  // Scene.cpp:110
         ps.o = rec.p;
         ps.d = reflected;
