@@ -1489,10 +1489,10 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
                 }
             }
         }
-        if (__ballot(active) == 0ull) {
-            if (next >= total) break;
-            continue;  // only slots outside the image were drawn (ragged edge tile)
-        }
+        // (no lane with an item although the pool is not spent: only slots outside the image were
+        // drawn on a ragged edge tile; the body below is harmless without items and the loop
+        // keeps a single back edge)
+        if (__ballot(active) == 0ull && next >= total) break;
         // Linear scan: no branch around the body.  A lane without an item (only while the pool
         // drains, or on a ragged edge tile) follows whatever ray it holds and its results are
         // thrown away; what that costs is nothing the wave would not execute anyway, and the
