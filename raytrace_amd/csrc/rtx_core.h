@@ -1238,11 +1238,13 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
             const float pdf1 = (cosine > 0.0f ? cosine : 0.0f) * (1.0f / kPi);  // = the scattering pdf
             const float pdf_value =
                 sc.n_lights != 0u ? 0.5f * light_pdf_fast(sc, rec.p, dir, len2, inv_len) + 0.5f * pdf1 : pdf1;
-            if (!(pdf_value > 0.0f)) return pin(ps);
-            ps.T = vmul(albedo, ps.T) * (pdf1 * frcp(pdf_value));
+            // the next ray is committed before the test: a path that ends here has no use for the
+            // old one either, and the old one's registers are free from this point on
             ps.o = rec.p;
             ps.d = dir;
             ps.depth += 1;
+            if (!(pdf_value > 0.0f)) return pin(ps);
+            ps.T = vmul(albedo, ps.T) * (pdf1 * frcp(pdf_value));
             return false;
         }
 #endif
@@ -1284,8 +1286,6 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
                 reflected = reflected + q * rec.param;
                 dir = reflected;
             }
-            if (!(dot(reflected, rec.n) > 0.0f)) return pin(ps);
-            ps.T = vmul(surface_color(sc, rec), ps.T);  // Scene.cpp:110
         } else {
             const float ri = rec.param;
             const bool inside = dn > 0.0f;
@@ -1307,6 +1307,10 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
         ps.o = rec.p;
         ps.d = dir;
         ps.depth += 1;
+        if (metal) {  // (tested after the commit of the next ray, as above)
+            if (!(dot(dir, rec.n) > 0.0f)) return pin(ps);
+            ps.T = vmul(surface_color(sc, rec), ps.T);  // Scene.cpp:110
+        }
         return false;
     }
 #endif
