@@ -209,6 +209,23 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* scene, uint32_t accel);
 int rtx_render(RtxContext* ctx, const RtxParams* params, float* accum_rgb, uint64_t* rays_out);
 
 /*
+ * The same frame on several GPUs from ONE process: the sample range
+ * [spp_begin, spp_begin+spp_count) is cut into n_ctx contiguous blocks (the first
+ * spp_count % n_ctx blocks one sample longer), block i is rendered by ctxs[i] on that
+ * context's device, all devices at the same time; the partial sums are copied
+ * device-to-device to ctxs[0]'s GPU and added there in context order, so the result does
+ * not depend on timing.  Samples are keyed by their absolute index: up to the order of the
+ * fp32 additions the frame is the one rtx_render makes on one GPU.  Every context must
+ * hold the same scene (rtx_upload_scene on each); two contexts may share a device.
+ * The reference has one loop nest on one host (Scene.cpp:137-153; its OpenMP pragma over
+ * pixels, Scene.cpp:139, is the nearest thing to a work split); this entry point is for C
+ * and C++ callers - Python callers use one process per GPU and torch.distributed instead.
+ *   accum_rgb / rays_out   as for rtx_render.
+ */
+int rtx_render_multi(RtxContext* const* ctxs, uint32_t n_ctx, const RtxParams* params, float* accum_rgb,
+                     uint64_t* rays_out);
+
+/*
  * Same, but the accumulator and the ray counter are DEVICE buffers on the
  * context's GPU and the work is enqueued on `hip_stream` (a hipStream_t, NULL =
  * the default stream) without waiting for it.  `d_rays` (optional, 8 bytes) is

@@ -97,11 +97,12 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("prim", "<i4"), ("t", "<f4"),
 RTX_SYMBOLS = (
     "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_device_count", "rtx_upload_scene",
     "rtx_render", "rtx_render_device", "rtx_render_samples", "rtx_hit", "rtx_resolve_device",
-    "rtx_scene_info",
+    "rtx_scene_info", "rtx_render_multi",
 )
 RTXH_SYMBOLS = (
     "rtxh_last_error", "rtxh_scene_create", "rtxh_scene_view", "rtxh_scene_destroy",
     "rtxh_image_write", "rtxh_resolve", "rtxh_write_bmp", "rtxh_render_to_bmp",
+    "rtxh_render_to_bmp_multi",
 )
 
 
@@ -153,6 +154,9 @@ def load_librtx() -> C.CDLL:
         lib.rtx_upload_scene.restype = C.c_int
         lib.rtx_render.argtypes = [ctxp, C.POINTER(RtxParams), C.c_void_p, C.POINTER(C.c_uint64)]
         lib.rtx_render.restype = C.c_int
+        lib.rtx_render_multi.argtypes = [C.POINTER(ctxp), C.c_uint32, C.POINTER(RtxParams), C.c_void_p,
+                                         C.POINTER(C.c_uint64)]
+        lib.rtx_render_multi.restype = C.c_int
         lib.rtx_render_device.argtypes = [ctxp, C.POINTER(RtxParams), C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rtx_render_device.restype = C.c_int
         lib.rtx_render_samples.argtypes = [ctxp, C.POINTER(RtxParams), C.c_void_p, C.c_void_p]
@@ -342,6 +346,22 @@ class Context:
         self._check(self._lib.rtx_resolve_device(self._ctx, width, height, ns, C.c_void_p(d_accum),
                                                  out.ctypes.data, C.c_void_p(stream) if stream else None))
         return out
+
+
+def render_multi(contexts, params: RtxParams, accum: Optional[np.ndarray] = None) -> Tuple[np.ndarray, int]:
+    """rtx_render_multi: one frame split by sample range over `contexts` (each holding the same
+    scene), summed on the first context's GPU; returns (sum image, rays)."""
+    lib = load_librtx()
+    if accum is None:
+        accum = np.zeros((params.height, params.width, 3), np.float32)
+    assert accum.dtype == np.float32 and accum.flags.c_contiguous
+    assert accum.shape == (params.height, params.width, 3)
+    handles = (C.c_void_p * len(contexts))(*[c._ctx for c in contexts])
+    rays = C.c_uint64(0)
+    rc = lib.rtx_render_multi(handles, len(contexts), C.byref(params), accum.ctypes.data, C.byref(rays))
+    if rc != RTX_OK:
+        raise RtxError(rc, lib.rtx_last_error().decode())
+    return accum, rays.value
 
 
 def device_count() -> int:

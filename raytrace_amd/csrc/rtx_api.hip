@@ -88,6 +88,7 @@ struct RtxContext {
     DeviceArray<float> ray_o, ray_d;
     DeviceArray<RtxHit> hits;
     DeviceArray<uint8_t> rgb8;
+    DeviceArray<float> peer_frames;  // rtx_render_multi: the other contexts' partial frames, on context 0's GPU
 };
 
 namespace {
@@ -684,6 +685,102 @@ int rtx_render(RtxContext* ctx, const RtxParams* params, float* accum_rgb, uint6
         RTX_HIP(hipMemcpy(&r, ctx->rays.ptr, sizeof r, hipMemcpyDeviceToHost));
         *rays_out = r;
     }
+    return RTX_OK;
+}
+
+namespace {
+struct EventList {  // events of one rtx_render_multi call, destroyed on every way out
+    std::vector<std::pair<int, hipEvent_t>> events;
+    ~EventList() {
+        for (auto& e : events) {
+            (void)hipSetDevice(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+    }
+};
+}  // namespace
+
+int rtx_render_multi(RtxContext* const* ctxs, uint32_t n_ctx, const RtxParams* params, float* accum_rgb,
+                     uint64_t* rays_out) {
+    if (!ctxs || n_ctx == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "no contexts");
+    if (n_ctx > 64) return fail(RTX_ERR_TOO_LARGE, "more than 64 contexts");
+    if (!accum_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "accumulator is null");
+    for (uint32_t i = 0; i < n_ctx; ++i) {
+        if (!ctxs[i]) return fail(RTX_ERR_INVALID_ARGUMENT, "a context is null");
+        for (uint32_t k = 0; k < i; ++k)
+            if (ctxs[k] == ctxs[i]) return fail(RTX_ERR_INVALID_ARGUMENT, "the same context is listed twice");
+        int rc = check_params(ctxs[i], params);
+        if (rc != RTX_OK) return rc;
+        if (ctxs[i]->info.n_prims != ctxs[0]->info.n_prims || ctxs[i]->info.accel != ctxs[0]->info.accel)
+            return fail(RTX_ERR_INVALID_ARGUMENT, "the contexts do not hold the same scene");
+    }
+    RtxContext* root = ctxs[0];
+    const size_t n = (size_t)params->width * params->height * 3;
+    const size_t bytes = n * sizeof(float);
+
+    // set-up on every device before anything is launched: buffers, counters, the caller's frame
+    for (uint32_t i = 0; i < n_ctx; ++i) {
+        RTX_HIP(hipSetDevice(ctxs[i]->device));
+        RTX_HIP(ctxs[i]->accum.resize(n));
+        RTX_HIP(ctxs[i]->rays.resize(1));
+        RTX_HIP(hipMemset(ctxs[i]->rays.ptr, 0, sizeof(unsigned long long)));
+        if (ctxs[i]->device != root->device) {
+            int can = 0;  // direct xGMI / PCIe peer writes where the platform has them; else the copy is staged by the runtime
+            if (hipDeviceCanAccessPeer(&can, ctxs[i]->device, root->device) == hipSuccess && can)
+                (void)hipDeviceEnablePeerAccess(root->device, 0);
+            (void)hipGetLastError();  // "already enabled" is not an error here
+        }
+    }
+    RTX_HIP(hipSetDevice(root->device));
+    if (n_ctx > 1) RTX_HIP(root->peer_frames.resize((size_t)(n_ctx - 1) * n));
+    if (params->accumulate) RTX_HIP(hipMemcpy(root->accum.ptr, accum_rgb, bytes, hipMemcpyHostToDevice));
+
+    // every device renders its block of the sample range; the launches do not wait for each other
+    const uint32_t base = params->spp_count / n_ctx, longer = params->spp_count % n_ctx;
+    uint32_t begin = params->spp_begin;
+    for (uint32_t i = 0; i < n_ctx; ++i) {
+        RtxParams p = *params;
+        p.spp_begin = begin;
+        p.spp_count = base + (i < longer ? 1u : 0u);
+        p.accumulate = i == 0 ? params->accumulate : 0u;
+        begin += p.spp_count;
+        if (p.spp_count == 0 && i != 0) {  // fewer samples than contexts: an empty partial frame
+            RTX_HIP(hipSetDevice(ctxs[i]->device));
+            RTX_HIP(hipMemsetAsync(ctxs[i]->accum.ptr, 0, bytes, nullptr));
+            continue;
+        }
+        int rc = rtx_render_device(ctxs[i], &p, ctxs[i]->accum.ptr, ctxs[i]->rays.ptr, nullptr);
+        if (rc != RTX_OK) return rc;
+    }
+
+    // partial frames to context 0's GPU (each over its own link, behind its own render), added
+    // there in context order
+    EventList done;
+    for (uint32_t i = 1; i < n_ctx; ++i) {
+        float* slot = root->peer_frames.ptr + (size_t)(i - 1) * n;
+        RTX_HIP(hipSetDevice(ctxs[i]->device));
+        RTX_HIP(hipMemcpyPeerAsync(slot, root->device, ctxs[i]->accum.ptr, ctxs[i]->device, bytes, nullptr));
+        hipEvent_t ev;
+        RTX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        done.events.emplace_back(ctxs[i]->device, ev);
+        RTX_HIP(hipEventRecord(ev, nullptr));
+    }
+    RTX_HIP(hipSetDevice(root->device));
+    for (uint32_t i = 1; i < n_ctx; ++i) {
+        RTX_HIP(hipStreamWaitEvent(nullptr, done.events[i - 1].second, 0));
+        RTX_HIP(rtx_post::launch_add(root->accum.ptr, root->peer_frames.ptr + (size_t)(i - 1) * n, n, nullptr));
+    }
+    RTX_HIP(hipDeviceSynchronize());
+    RTX_HIP(hipMemcpy(accum_rgb, root->accum.ptr, bytes, hipMemcpyDeviceToHost));
+    unsigned long long total = 0;
+    for (uint32_t i = 0; i < n_ctx; ++i) {
+        RTX_HIP(hipSetDevice(ctxs[i]->device));
+        RTX_HIP(hipDeviceSynchronize());
+        unsigned long long r = 0;
+        RTX_HIP(hipMemcpy(&r, ctxs[i]->rays.ptr, sizeof r, hipMemcpyDeviceToHost));
+        total += r;
+    }
+    if (rays_out) *rays_out = total;
     return RTX_OK;
 }
 

@@ -18,4 +18,6 @@ namespace rtx_post {
 // sum / ns -> NaN filter -> gamma -> clamp -> 8 bit (Scene.cpp:150-151, Image.h:30-39)
 hipError_t launch_resolve(const float* d_accum, uint8_t* d_rgb8, uint32_t n_pixels, uint32_t ns,
                           hipStream_t stream);
+// dst[k] += src[k]: a partial frame of another GPU added to this one's (fp32, as Scene.cpp:148 adds)
+hipError_t launch_add(float* d_dst, const float* d_src, size_t n, hipStream_t stream);
 }  // namespace rtx_post

@@ -4,6 +4,8 @@
 // (TonemapFilter.h:8-10, clamp to [0,1]), then c * 255.99f truncated to 8 bits
 // (Image.h:36-38).
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 
 #include "rtx_launch.h"
@@ -35,6 +37,28 @@ __global__ void __launch_bounds__(256) resolve_kernel(const float* __restrict__ 
     rgb8[3u * k + 0u] = (uint8_t)(r * 255.99f);
     rgb8[3u * k + 1u] = (uint8_t)(g * 255.99f);
     rgb8[3u * k + 2u] = (uint8_t)(b * 255.99f);
+}
+
+__global__ void __launch_bounds__(256) add_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    // grid-stride, one float4 per step where the length allows; HBM bound: 12 bytes per element
+    const size_t n4 = n / 4u;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += stride) {
+        float4 a = d4[k];
+        const float4 b = s4[k];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        d4[k] = a;
+    }
+    for (size_t k = 4u * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) dst[k] += src[k];
+}
+
+hipError_t launch_add(float* d_dst, const float* d_src, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const size_t blocks = std::min<size_t>((n / 4u + 255u) / 256u + 1u, 256u * 16u);
+    hipLaunchKernelGGL(add_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_dst, d_src, n);
+    return hipGetLastError();
 }
 
 hipError_t launch_resolve(const float* d_accum, uint8_t* d_rgb8, uint32_t n_pixels, uint32_t ns,

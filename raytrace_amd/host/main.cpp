@@ -5,9 +5,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 extern "C" int rtxh_render_to_bmp(const char* name, const char* path, int w, int h, int spp, int deterministic,
                                   unsigned long long seed, int device, unsigned long long* rays, double* seconds);
+extern "C" int rtxh_render_to_bmp_multi(const char* name, const char* path, int w, int h, int spp, int deterministic,
+                                        unsigned long long seed, const int* devices, int n_devices,
+                                        unsigned long long* rays, double* seconds);
 extern "C" const char* rtxh_last_error(void);
 
 int main(int argc, char** argv) {
@@ -15,6 +19,7 @@ int main(int argc, char** argv) {
     int nx = 800, ny = 400, ns = 50, det = 0, device = 0;
     unsigned long long seed = 0;
     std::string scene = "cornell_builtin", out = "Output/40_Test.bmp";
+    std::vector<int> devices;  // --devices 0,1,2,...: the frame split by sample range over these GPUs
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&](const char* what) -> const char* {
@@ -28,17 +33,30 @@ int main(int argc, char** argv) {
         else if (a == "--spp") ns = std::atoi(next("--spp"));
         else if (a == "--seed") seed = std::strtoull(next("--seed"), nullptr, 10);
         else if (a == "--device") device = std::atoi(next("--device"));
+        else if (a == "--devices") {
+            const char* list = next("--devices");
+            for (const char* q = list; *q;) {
+                char* end = nullptr;
+                devices.push_back((int)std::strtol(q, &end, 10));
+                if (end == q) { std::fprintf(stderr, "bad --devices list '%s'\n", list); return 2; }
+                q = *end == ',' ? end + 1 : end;
+            }
+        }
         else if (a == "--deterministic") det = 1;
         else {
             std::fprintf(stderr,
                          "usage: %s [--scene NAME] [--out FILE.bmp] [--width W] [--height H] [--spp N]\n"
-                         "          [--seed S] [--device D] [--deterministic]\n", argv[0]);
+                         "          [--seed S] [--device D | --devices D0,D1,...] [--deterministic]\n", argv[0]);
             return 2;
         }
     }
     unsigned long long rays = 0;
     double seconds = 0.0;
-    if (!rtxh_render_to_bmp(scene.c_str(), out.c_str(), nx, ny, ns, det, seed, device, &rays, &seconds)) {
+    const int ok = devices.empty()
+                       ? rtxh_render_to_bmp(scene.c_str(), out.c_str(), nx, ny, ns, det, seed, device, &rays, &seconds)
+                       : rtxh_render_to_bmp_multi(scene.c_str(), out.c_str(), nx, ny, ns, det, seed, devices.data(),
+                                                  (int)devices.size(), &rays, &seconds);
+    if (!ok) {
         std::fprintf(stderr, "render failed: %s\n", rtxh_last_error());
         return 1;
     }

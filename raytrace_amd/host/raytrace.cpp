@@ -666,34 +666,40 @@ bool Scene::render() {
         return false;
     }
     const int nx = m_image->width(), ny = m_image->height();
-    RtxContext* ctx = nullptr;
-    if (rtx_create(m_device, &ctx) != RTX_OK) {
-        m_error = rtx_last_error();
-        return false;
+    const std::vector<int> devices = m_devices.empty() ? std::vector<int>{m_device} : m_devices;
+    std::vector<RtxContext*> ctxs;
+    bool ok = true;
+    for (int d : devices) {
+        RtxContext* ctx = nullptr;
+        ok = rtx_create(d, &ctx) == RTX_OK && (ctxs.push_back(ctx), true) &&
+             rtx_upload_scene(ctx, flat.view(), RTX_ACCEL_AUTO) == RTX_OK;
+        if (!ok) break;
     }
-    bool ok = rtx_upload_scene(ctx, flat.view(), RTX_ACCEL_AUTO) == RTX_OK;
     std::vector<float> accum((size_t)nx * ny * 3, 0.0f);
     m_rays = 0;
     auto t0 = std::chrono::steady_clock::now();
+    // a launch is m_samplesPerLaunch samples per pixel on EACH device
+    const int per_call = m_samplesPerLaunch * (int)devices.size();
     for (int done = 0; ok && done < m_samples;) {
         RtxParams p;
         std::memset(&p, 0, sizeof p);
         p.width = (uint32_t)nx;
         p.height = (uint32_t)ny;
         p.spp_begin = (uint32_t)done;
-        p.spp_count = (uint32_t)std::min(m_samplesPerLaunch, m_samples - done);
+        p.spp_count = (uint32_t)std::min(per_call, m_samples - done);
         p.max_depth = (uint32_t)m_maxDepth;
         p.mode = m_deterministic ? RTX_MODE_DETERMINISTIC : RTX_MODE_FAST;
         p.seed = m_seed;
         p.accumulate = done > 0 ? 1u : 0u;
         uint64_t rays = 0;
-        ok = rtx_render(ctx, &p, accum.data(), &rays) == RTX_OK;
+        ok = (ctxs.size() == 1 ? rtx_render(ctxs[0], &p, accum.data(), &rays)
+                               : rtx_render_multi(ctxs.data(), (uint32_t)ctxs.size(), &p, accum.data(), &rays)) == RTX_OK;
         m_rays += rays;
         done += (int)p.spp_count;
     }
     m_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (!ok) m_error = rtx_last_error();
-    rtx_destroy(ctx);
+    for (RtxContext* ctx : ctxs) rtx_destroy(ctx);
     if (!ok) return false;
     // Scene.cpp:150-151: c /= ns, then the filter chain; accumulator rows are already
     // top-first.

@@ -464,6 +464,10 @@ public:
     void setSeed(uint64_t s) { m_seed = s; }
     void setDeterministic(bool d) { m_deterministic = d; }
     void setDevice(int d) { m_device = d; }
+    // Several GPUs of this host: each renders a contiguous block of every launch's sample range
+    // and the partial frames are summed on the first one (rtx_render_multi).  An empty list
+    // (the default) means the single device of setDevice().
+    void setDevices(const std::vector<int>& d) { m_devices = d; }
     void setSamplesPerLaunch(int s) { m_samplesPerLaunch = s; }
 
     // Flatten camera / world / light into `out`.  False on a scene the GPU path
@@ -488,6 +492,7 @@ protected:
     uint64_t m_seed = 0;
     bool m_deterministic = false;
     int m_device = 0;
+    std::vector<int> m_devices;
     int m_samplesPerLaunch = 64;
     std::string m_error;
     unsigned long long m_rays = 0;

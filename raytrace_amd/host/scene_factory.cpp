@@ -118,4 +118,25 @@ int rtxh_render_to_bmp(const char* name, const char* path, int w, int h, int spp
     return 1;
 }
 
+// The same on several GPUs of this host (Scene::setDevices).
+int rtxh_render_to_bmp_multi(const char* name, const char* path, int w, int h, int spp, int deterministic,
+                             uint64_t seed, const int* devices, int n_devices, unsigned long long* rays,
+                             double* seconds) {
+    if (!devices || n_devices <= 0) {
+        g_error = "no devices";
+        return 0;
+    }
+    NamedScene scene(name, path, w, h, spp);
+    scene.setDeterministic(deterministic != 0);
+    scene.setSeed(seed);
+    scene.setDevices(std::vector<int>(devices, devices + n_devices));
+    if (!scene.render()) {
+        g_error = scene.built() ? scene.lastError() : std::string("unknown scene '") + name + "'";
+        return 0;
+    }
+    if (rays) *rays = scene.raysTraced();
+    if (seconds) *seconds = scene.renderSeconds();
+    return 1;
+}
+
 }  // extern "C"

@@ -217,6 +217,47 @@ def test_sample_ranges_and_accumulate_compose(gpu_ctx):
         assert np.allclose(both, a + b, rtol=1e-6, atol=1e-7)
 
 
+def test_render_multi_splits_the_sample_range_and_sums_in_context_order(gpu_ctx):
+    """rtx_render_multi over three contexts (the test box has one GPU: they share it, which
+    exercises the same split, peer copies and ordered additions) against one rtx_render."""
+    w, h = 83, 47
+    scene = api.HostScene("cornell_extra", w, h)
+    gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+    others = [api.Context(0), api.Context(0)]
+    try:
+        for c in others:
+            c.upload(scene, api.RTX_ACCEL_LINEAR)
+        group = [gpu_ctx] + others
+        for mode in (api.RTX_MODE_DETERMINISTIC, api.RTX_MODE_FAST):
+            p = gpu_ctx.params(w, h, 5, 11, mode=mode, seed=3)  # 11 samples: blocks of 4, 4, 3
+            whole, rays = gpu_ctx.render(p)
+            parts = [gpu_ctx.render(gpu_ctx.params(w, h, b, n, mode=mode, seed=3)) for b, n in ((5, 4), (9, 4), (13, 3))]
+            got, got_rays = api.render_multi(group, p)
+            assert got_rays == rays == sum(r for _, r in parts)
+            # bit-identical to the blocks added in context order; the one-pass frame differs
+            # from that by the order of the fp32 additions only
+            assert np.array_equal(got, (parts[0][0] + parts[1][0]) + parts[2][0])
+            assert np.allclose(got, whole, rtol=1e-5, atol=1e-6)
+            # accumulate: the caller's frame is the starting value
+            more, _ = api.render_multi(group, gpu_ctx.params(w, h, 16, 2, mode=mode, seed=3, accumulate=True), got.copy())
+            two, _ = gpu_ctx.render(gpu_ctx.params(w, h, 16, 2, mode=mode, seed=3))
+            assert np.allclose(more, got + two, rtol=1e-5, atol=1e-6)
+            # fewer samples than contexts: the empty blocks add nothing
+            one, rays1 = api.render_multi(group, gpu_ctx.params(w, h, 0, 1, mode=mode, seed=3))
+            ref1, ref_rays1 = gpu_ctx.render(gpu_ctx.params(w, h, 0, 1, mode=mode, seed=3))
+            assert rays1 == ref_rays1 and np.array_equal(one, ref1)
+        # one context: the same as rtx_render
+        solo, _ = api.render_multi([gpu_ctx], gpu_ctx.params(w, h, 0, 3, seed=3))
+        assert np.array_equal(solo, gpu_ctx.render(gpu_ctx.params(w, h, 0, 3, seed=3))[0])
+        with pytest.raises(api.RtxError):
+            api.render_multi([gpu_ctx, gpu_ctx], p)  # the same context twice
+        with pytest.raises(api.RtxError):
+            api.render_multi([gpu_ctx, api.Context(0)], p)  # a context without a scene
+    finally:
+        for c in others:
+            c.close()
+
+
 def test_edge_cases(gpu_ctx):
     scene = api.HostScene("cornell", 17, 9)  # ragged: not a multiple of the 16x16 tile
     gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
