@@ -1590,7 +1590,7 @@ constexpr uint32_t kLeafBatch = RTX_LEAF_BATCH;
 #define RTX_BVH_BLOCK 64
 #endif
 #ifndef RTX_BVH_WAVES
-#define RTX_BVH_WAVES 5  // minimum resident waves per SIMD the kernel is compiled for
+#define RTX_BVH_WAVES 6  // minimum resident waves per SIMD the kernel is compiled for (80 VGPRs, none spilled; 5: 82)
 #endif
 
 template <bool kLightTree>
