@@ -72,6 +72,7 @@ struct RtxContext {
     DeviceArray<uint8_t> texels;
     DeviceArray<rtxd::Light> lights;
     DeviceArray<rtxd::LightNode> light_nodes;
+    DeviceArray<rtxd::LightBvhNode> light_bvh;
     DeviceArray<rtxd::ScanGroup> scan_groups;
     DeviceArray<rtxd::ScanRec> scan_recs;
     DeviceArray<rtxd::ScanHit> scan_info;
@@ -532,6 +533,35 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
             if (N.step_end > N.step_begin || E.kind == RTX_LIGHT_RECT_XY || E.kind == RTX_LIGHT_RECT_YZ) light_tree = true;
         }
     }
+    // many light leaves with a density of their own: a tree over them, so that the density sum of
+    // a diffuse bounce visits the leaves the sampled direction meets instead of all of them
+    std::vector<rtxd::LightBvhNode> light_bvh;
+    {
+        std::vector<rtxd::Prim> shapes;
+        std::vector<rtxd::Group> chains;
+        std::vector<uint32_t> entries;
+        for (uint32_t l = 0; l < n_light_entries; ++l) {
+            const rtxd::Light& E = lights[l];
+            const bool has_density = E.kind == RTX_LIGHT_SPHERE || E.kind == RTX_LIGHT_RECT_XZ ||
+                                     (general_lights && E.kind <= RTX_LIGHT_RECT_YZ);
+            if (!has_density) continue;
+            rtxd::Prim P{};
+            P.a = E.a; P.b = E.b; P.c = E.c; P.d = E.d; P.e = E.e;
+            P.kind_flip = E.kind;  // RTX_LIGHT_RECT_* / SPHERE = RTX_PRIM_*
+            rtxd::Group G{};
+            G.prim_begin = (uint32_t)shapes.size();
+            G.prim_end = G.prim_begin + 1u;
+            G.step_begin = light_nodes[l].step_begin;
+            G.step_end = light_nodes[l].step_end;
+            shapes.push_back(P);
+            chains.push_back(G);
+            entries.push_back(l);
+        }
+        if (entries.size() >= RTX_LIGHT_BVH_MIN) {
+            rtxbvh::build_light_tree(shapes, chains, steps, entries, light_bvh);
+            light_tree = true;  // the kernels that know the tree
+        }
+    }
     // one record per primitive with all the integrator needs after a hit
     std::vector<rtxd::PrimInfo> info(s->n_prims);
     for (uint32_t p = 0; p < s->n_prims; ++p) {
@@ -585,6 +615,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     RTX_HIP(ctx->texels.upload(std::vector<uint8_t>(s->texels, s->texels + s->n_texel_bytes)));
     RTX_HIP(ctx->lights.upload(lights));
     RTX_HIP(ctx->light_nodes.upload(light_nodes));
+    RTX_HIP(ctx->light_bvh.upload(light_bvh));
     RTX_HIP(ctx->scan_groups.upload(scan_groups));
     RTX_HIP(ctx->scan_recs.upload(scan_recs));
     RTX_HIP(ctx->scan_info.upload(scan_info));
@@ -628,6 +659,9 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     v.light_nodes = ctx->light_nodes.ptr;
     v.n_light_entries = n_light_entries;
     v.light_flags = (general_lights ? rtxd::kLightsGeneral : 0u) | (light_tree ? rtxd::kLightsTree : 0u);
+    v.light_bvh = light_bvh.empty() ? nullptr : ctx->light_bvh.ptr;
+    v.n_light_bvh = (uint32_t)light_bvh.size();
+    v.light_bvh_pad_ = 0;
     std::memcpy(v.cam_origin, s->cam_origin, sizeof v.cam_origin);
     std::memcpy(v.cam_ll, s->cam_ll, sizeof v.cam_ll);
     std::memcpy(v.cam_u, s->cam_u, sizeof v.cam_u);

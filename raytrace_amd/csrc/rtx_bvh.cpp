@@ -327,4 +327,54 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
     return true;
 }
 
+namespace {
+struct LightItem {
+    Box box;
+    double centre[3];
+    uint32_t entry;
+};
+
+// Emits the subtree over items [begin, end) at out.size() and returns nothing: the caller reads
+// the subtree's extent from out.size() afterwards.
+void emit_light_subtree(std::vector<LightItem>& items, size_t begin, size_t end, std::vector<rtxd::LightBvhNode>& out) {
+    Box box;
+    for (size_t k = begin; k < end; ++k) box.add(items[k].box);
+    const size_t self = out.size();
+    out.emplace_back();
+    for (int a = 0; a < 3; ++a) {
+        out[self].lo[a] = std::nextafterf((float)box.lo[a], -FLT_MAX);  // double -> float, outwards
+        out[self].hi[a] = std::nextafterf((float)box.hi[a], FLT_MAX);
+    }
+    if (end - begin == 1) {
+        out[self].entry = items[begin].entry;
+    } else {
+        out[self].entry = rtxd::kLightBvhInner;
+        Box centres;
+        for (size_t k = begin; k < end; ++k) centres.add(items[k].centre);
+        int axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (centres.hi[a] - centres.lo[a] > centres.hi[axis] - centres.lo[axis]) axis = a;
+        const size_t mid = begin + (end - begin) / 2;
+        std::nth_element(items.begin() + begin, items.begin() + mid, items.begin() + end,
+                         [axis](const LightItem& x, const LightItem& y) { return x.centre[axis] < y.centre[axis]; });
+        emit_light_subtree(items, begin, mid, out);  // depth log2(n): the halves are equal
+        emit_light_subtree(items, mid, end, out);
+    }
+    out[self].skip = (uint32_t)out.size();
+}
+}  // namespace
+
+void build_light_tree(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,
+                      const std::vector<rtxd::Step>& steps, const std::vector<uint32_t>& entries,
+                      std::vector<rtxd::LightBvhNode>& out) {
+    out.clear();
+    std::vector<LightItem> items(groups.size());
+    for (size_t g = 0; g < groups.size(); ++g) {
+        items[g].box = group_box(prims, groups[g], steps);
+        for (int a = 0; a < 3; ++a) items[g].centre[a] = 0.5 * (items[g].box.lo[a] + items[g].box.hi[a]);
+        items[g].entry = entries[g];
+    }
+    if (!items.empty()) emit_light_subtree(items, 0, items.size(), out);
+}
+
 }  // namespace rtxbvh

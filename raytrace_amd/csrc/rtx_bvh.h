@@ -37,4 +37,12 @@ struct Tree {
 bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,
            const std::vector<rtxd::Step>& steps, Tree& out, std::string& err);
 
+// Tree over the light leaves for the density sum (rtxd::LightBvhNode): group g of `groups` is
+// one light leaf (its shape as a primitive, its transform chain), `entries[g]` the index the
+// leaf's node carries.  Median splits on the widest axis of the centres, one leaf per node,
+// boxes padded like the scene tree's; nodes come out in depth-first order with skip links.
+void build_light_tree(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,
+                      const std::vector<rtxd::Step>& steps, const std::vector<uint32_t>& entries,
+                      std::vector<rtxd::LightBvhNode>& out);
+
 }  // namespace rtxbvh

@@ -1075,6 +1075,37 @@ RTX_DEV float light_pdf_leaf(const Light& E, V3 o, V3 v, bool general) {
 RTX_DEV float light_pdf_tree(const SceneView& sc, V3 o, V3 v) {
     const bool general = (sc.light_flags & kLightsGeneral) != 0u;
     float sum = 0.0f;
+    if (sc.n_light_bvh != 0u) {
+        // Many lights: only the leaves whose box the ray (o, v), t >= t_min, meets can answer
+        // anything but 0.  Per lane, stackless: depth-first order with skip links.  The terms are
+        // added in the tree's order, not the list's: the same sum up to rounding.
+        constexpr float kBig = 1.0e18f;  // a direction component of zero: keep the reciprocal finite
+        const V3 inv = v3(__builtin_amdgcn_fmed3f(frcp(v.x), -kBig, kBig), __builtin_amdgcn_fmed3f(frcp(v.y), -kBig, kBig),
+                          __builtin_amdgcn_fmed3f(frcp(v.z), -kBig, kBig));
+        const V3 noi = v3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+        uint32_t i = 0u;
+        while (i < sc.n_light_bvh) {
+            const LightBvhNode B = sc.light_bvh[i];
+            const float tx0 = __builtin_fmaf(B.lo[0], inv.x, noi.x), tx1 = __builtin_fmaf(B.hi[0], inv.x, noi.x);
+            const float ty0 = __builtin_fmaf(B.lo[1], inv.y, noi.y), ty1 = __builtin_fmaf(B.hi[1], inv.y, noi.y);
+            const float tz0 = __builtin_fmaf(B.lo[2], inv.z, noi.z), tz1 = __builtin_fmaf(B.hi[2], inv.z, noi.z);
+            const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
+            const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+            if (!(tn <= tf)) {
+                i = B.skip;
+                continue;
+            }
+            if (B.entry != kLightBvhInner) {
+                const Light E = sc.lights[B.entry];
+                const LightNode N = sc.light_nodes[B.entry];
+                V3 ol = o, vl = v;
+                enter_group<false>(sc, N.step_begin, N.step_end, ol, vl);
+                sum = sum + N.weight * light_pdf_leaf(E, ol, vl, general);
+            }
+            ++i;  // the first child, or the node after a leaf (= its skip link)
+        }
+        return sum;
+    }
     // consecutive leaves under the same chain (the six faces of a box) share the transformed query
     uint32_t cur_begin = 0u, cur_end = 0u;
     V3 ol = o, vl = v;

@@ -117,6 +117,26 @@ struct alignas(32) LightNode {
     float weight;                   // product of the 1 / n of every list above the entry
     uint32_t pad[3];
 };
+// Many lights: a bounding-volume tree over the light leaves in depth-first order with skip
+// links.  ShapeList::pdf_value (ShapeList.cpp:19-26) asks EVERY entry for its density along
+// (o, v), and an entry answers 0 unless the ray meets it (Rect.cpp:38-40, Sphere.cpp:40-42): the
+// sum only has to visit the leaves whose box the ray meets.  A query wants all of them, in any
+// order, so it needs no stack: at node i go to i + 1 (the first child, or past a leaf) when the
+// ray meets the box, to `skip` (the node after i's whole subtree) when it does not.
+struct alignas(32) LightBvhNode {
+    float lo[3];
+    uint32_t skip;   // index of the node after this one's subtree (n_light_bvh = the end)
+    float hi[3];
+    uint32_t entry;  // leaf: index into lights[] / light_nodes[]; inner node: kLightBvhInner
+};
+constexpr uint32_t kLightBvhInner = 0xffffffffu;
+#ifndef RTX_LIGHT_BVH_MIN
+// Light leaves from which the tree is built and used.  Below it the plain sum over wave-uniform
+// (scalar-loaded) records is faster than the per-lane walk: measured on a Cornell room with k x k
+// ceiling lamps, 68 lights 23.8 ms (sum) / 25.8 ms (tree), 104 lights 30.4 / 28.8, 260 lights
+// 46.9 / 27.9, 1 604 lights 271 / 45 (1080p, 64 samples per pixel).
+#define RTX_LIGHT_BVH_MIN 96
+#endif
 constexpr uint32_t kLightsGeneral = 1u;  // SceneView::light_flags: RTX_LIGHTS_GENERAL semantics
 constexpr uint32_t kLightsTree = 2u;     // nested lists, chains or XY / YZ rect lights present: tree kernels
 
@@ -189,6 +209,9 @@ struct SceneView {
     float cam_origin[3], cam_ll[3], cam_u[3], cam_v[3];
     float background[3];
     uint32_t background_mode;  // RTX_BACKGROUND_*
+    const LightBvhNode* light_bvh;  // null: light_pdf_tree visits every leaf
+    uint32_t n_light_bvh;
+    uint32_t light_bvh_pad_;
 };
 
 struct TraceArgs {

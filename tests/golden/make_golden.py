@@ -36,6 +36,8 @@ SAMPLE_CASES = [  # scene, w, h, spp_begin, spp, seed
     ("sky_spheres", 48, 27, 0, 8, 7),  # no light shape + sky: from the CPU restatement (see RESTATEMENT_ONLY)
     ("cornell_light_tree", 48, 27, 0, 8, 7),   # nested light lists, XY rect / wrapped shapes with the default density
     ("cornell_side_lights", 48, 27, 0, 8, 7),  # general light sampling: from the CPU restatement
+    ("cornell_many_lights", 48, 27, 0, 8, 7),  # a flat list of 40 lights
+    ("cornell_many_lights_10", 40, 22, 0, 4, 7),  # 104 lights: the GPU sums their densities through a tree
 ]
 # Scenes the reference's color() cannot render (it dereferences its light, Scene.cpp:113, and
 # never calls backgroundSky): their vectors come from oracle/restate.cpp, whose pieces for this

@@ -154,7 +154,8 @@ def test_builtin_scene_equals_transcribed_scene():
 @needs_ref
 def test_reference_and_restatement_agree_on_fresh_inputs():
     for name, w, h, spp, seed in (("cornell_extra", 36, 20, 6, 1234), ("random_field", 30, 16, 3, 99),
-                                  ("textured", 40, 22, 5, 31), ("cornell_light_tree", 40, 22, 6, 5)):
+                                  ("textured", 40, 22, 5, 31), ("cornell_light_tree", 40, 22, 6, 5),
+                                  ("cornell_many_lights", 40, 22, 6, 5)):
         scene = api.HostScene(name, w, h)
         a = restate.render(scene, w, h, 10, spp, seed=seed, threads=4, per_sample=True)
         b = ref.RefScene(name, w, h).render(10, spp, seed=seed, threads=4, per_sample=True)

@@ -51,6 +51,9 @@ def _compare_samples(got_rgb, got_seg, want_rgb, want_seg):
     ("textured", 64, 36, 8, api.RTX_ACCEL_BVH),
     ("cornell_light_tree", 64, 36, 8, api.RTX_ACCEL_LINEAR),  # nested light lists, shapes with the default density
     ("cornell_light_tree", 64, 36, 8, api.RTX_ACCEL_BVH),
+    ("cornell_many_lights", 64, 36, 8, api.RTX_ACCEL_LINEAR),  # 40 lights in a flat list: the plain density sum
+    ("cornell_many_lights_10", 48, 27, 6, api.RTX_ACCEL_LINEAR),  # 104 lights: the density sum walks the light tree
+    ("cornell_many_lights_10", 48, 27, 6, api.RTX_ACCEL_BVH),
 ])
 def test_deterministic_samples_match_reference(gpu_ctx, name, w, h, spp, accel):
     ref = _ref()
@@ -332,7 +335,8 @@ def test_fast_mode_hits_agree_with_golden_up_to_rounding(gpu_ctx, name, accel):
     assert du.max() < 5e-3
 
 
-@pytest.mark.parametrize("name", ["textured", "sky_spheres", "cornell_light_tree", "cornell_side_lights"])
+@pytest.mark.parametrize("name", ["textured", "sky_spheres", "cornell_light_tree", "cornell_side_lights",
+                                  "cornell_many_lights_10"])
 def test_fast_mode_converges_on_widened_scenes(gpu_ctx, name):
     """Image textures / sky background without a light shape / light trees / general light
     sampling in fast mode: the estimator of the CPU tracer on the same scene (mean squared error
