@@ -493,7 +493,7 @@ protected:
     bool m_deterministic = false;
     int m_device = 0;
     std::vector<int> m_devices;
-    int m_samplesPerLaunch = 64;
+    int m_samplesPerLaunch = 512;  // per device; each rtx_render call also moves the frame over PCIe twice
     std::string m_error;
     unsigned long long m_rays = 0;
     double m_seconds = 0.0;
