@@ -88,6 +88,19 @@ class RefScene:
         assert rc == 0
         return {"hit": hit, "t": t, "p": p, "n": nrm, "uv": uv, "mat_kind": mk}
 
+    def light_pdf(self, origins, directions, seed=0):
+        """Shape::pdf_value(o, v) of the scene's light shape and Shape::random(o), entry k drawing
+        from the stream of (pixel k, sample 0, seed).  Returns (values, directions)."""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        vals = np.zeros(o.shape[0], np.float32)
+        dirs = np.zeros_like(o)
+        rc = self.lib.ref_light_pdf(C.c_void_p(self.handle), C.c_int(o.shape[0]), C.c_void_p(o.ctypes.data),
+                                    C.c_void_p(d.ctypes.data), C.c_uint64(seed), C.c_void_p(vals.ctypes.data),
+                                    C.c_void_p(dirs.ctypes.data))
+        assert rc == 0
+        return vals, dirs
+
     def camera_rays(self, uv):
         a = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
         o = np.zeros((a.shape[0], 3), np.float32)

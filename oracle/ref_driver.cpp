@@ -290,4 +290,22 @@ int ref_cosine_pdf(int n, const float* normals, uint64_t seed, float* dirs, floa
     }
     return 0;
 }
+/* Shape::pdf_value / Shape::random of the scene's light shape (ShapeList.cpp:19-35,
+ * Rect.cpp:36-68, Sphere.cpp:38-58, Shape.h:8-9) for n (origin, direction) pairs; entry k draws
+ * its random() from the stream of (pixel k, sample 0, seed). */
+int ref_light_pdf(void* p, int n, const float* org, const float* dir, uint64_t seed, float* values, float* dirs) {
+    RefScene* rs = static_cast<RefScene*>(p);
+    if (!rs || !rs->light) return -1;
+    for (int k = 0; k < n; ++k) {
+        const Vector3 o(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
+        const Vector3 v(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);
+        values[k] = rs->light->pdf_value(o, v);
+        rtx_rng_init(&g_rt_rng, uint32_t(k), 0u, seed);
+        const Vector3 d = rs->light->random(o);
+        dirs[3 * k] = d.getX();
+        dirs[3 * k + 1] = d.getY();
+        dirs[3 * k + 2] = d.getZ();
+    }
+    return 0;
+}
 }  // extern "C"

@@ -922,4 +922,21 @@ int restate_cosine_pdf(int n, const float* normals, uint64_t seed, float* dirs, 
     }
     return 0;
 }
+
+/* ShapePdf::value / generate of the scene's light shape (ShapePdf.h:8-17 -> ShapeList.cpp:19-35,
+ * Rect.cpp:36-68, Sphere.cpp:38-58, Shape.h:8-9) for n (origin, direction) pairs; entry k draws
+ * from the stream of (pixel k, sample 0, seed). */
+int restate_light_pdf(const RtxScene* scene, int n, const float* org, const float* dir, uint64_t seed, float* values,
+                      float* dirs) {
+    if (!scene || scene->n_lights == 0) return -1;
+    Tracer<float> tr(*scene, 50);
+    for (int k = 0; k < n; ++k) {
+        const Vec<float> o(org[3 * k], org[3 * k + 1], org[3 * k + 2]), v(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);
+        values[k] = tr.light_pdf(o, v);
+        rtx_rng_init(&tr.rng, uint32_t(k), 0u, seed);
+        const Vec<float> d = tr.light_random(o);
+        dirs[3 * k] = d.x; dirs[3 * k + 1] = d.y; dirs[3 * k + 2] = d.z;
+    }
+    return 0;
+}
 }  // extern "C"

@@ -118,6 +118,21 @@ def background_sky(dirs):
     return out
 
 
+def light_pdf(scene, origins, directions, seed=0):
+    """ShapePdf::value / generate of the scene's light shape for n (origin, direction) pairs; entry
+    k draws from the stream of (pixel k, sample 0, seed).  Returns (values, directions)."""
+    lib = load()
+    o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+    vals = np.zeros(o.shape[0], np.float32)
+    dirs = np.zeros_like(o)
+    rc = lib.restate_light_pdf(_scene_ptr(scene), C.c_int(o.shape[0]), C.c_void_p(o.ctypes.data),
+                               C.c_void_p(d.ctypes.data), C.c_uint64(seed), C.c_void_p(vals.ctypes.data),
+                               C.c_void_p(dirs.ctypes.data))
+    assert rc == 0
+    return vals, dirs
+
+
 def cosine_pdf(normals, seed=0):
     """CosinePdf::generate / value (CosinePdf.cpp:6-20) around n normals; entry k draws from the
     stream of (pixel k, sample 0, seed).  Returns (directions, values)."""

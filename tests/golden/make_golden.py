@@ -85,7 +85,7 @@ def rays_for(name, n, rng):
 
 def main(argv):
     assert ref.available(), "build oracle/_ref first"
-    sections = argv or ["texture", "samples", "hits", "misc", "pieces", "flops", "gt"]
+    sections = argv or ["texture", "samples", "hits", "misc", "pieces", "lights", "flops", "gt"]
 
     def want(section, scene=None):
         return section in sections or (scene is not None and f"{section}:{scene}" in sections)
@@ -130,10 +130,44 @@ def main(argv):
         misc(np.random.default_rng(2026))
     if want("pieces"):
         pieces(np.random.default_rng(2027))
+    if want("lights"):
+        light_pieces(np.random.default_rng(2029))
     if want("flops"):
         flops_per_ray()
     if want("gt"):
         ground_truth()
+
+
+LIGHT_SCENES = ("cornell", "small", "cornell_light_tree", "cornell_many_lights")
+
+
+def light_queries(name, n, rng):
+    """(origin, direction) pairs for the light shape's density: origins inside the scene, half the
+    directions towards a point the light shape itself proposes (so the density is not 0)."""
+    scene = ref.RefScene(name, 32, 32)
+    if name == "small":
+        o = rng.uniform([-6, 0.1, -6], [6, 4, 6], size=(n, 3)).astype(np.float32)
+    else:
+        o = rng.uniform(5, 550, size=(n, 3)).astype(np.float32)
+    v = rng.normal(size=(n, 3)).astype(np.float32)
+    _, towards = scene.light_pdf(o, v, seed=99)
+    aim = rng.random(n) < 0.5
+    v[aim] = towards[aim]
+    v[::17, 1] = 0.0  # parallel to the XZ lamps: the division by v.y (Rect.cpp:38)
+    return scene, o, v
+
+
+def light_pieces(rng):
+    """Shape::pdf_value / random of whole light shapes (flat list, one sphere, nested lists with
+    shapes of default density, a list of 40), function by function."""
+    out = {}
+    for name in LIGHT_SCENES:
+        scene, o, v = light_queries(name, 1024, rng)
+        vals, dirs = scene.light_pdf(o, v, seed=2028)
+        out[name + "_o"], out[name + "_v"], out[name + "_values"], out[name + "_dirs"] = o, v, vals, dirs
+        print("light", name, int((vals > 0).sum()), "of", vals.size, "non-zero")
+    out["seed"] = np.uint64(2028)
+    np.savez_compressed(os.path.join(HERE, "light_pdf.npz"), **out)
 
 
 def pieces(rng):

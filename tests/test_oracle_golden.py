@@ -83,6 +83,19 @@ def test_restatement_sky_and_cosine_pdf_match_reference():
     assert (vals > 0).all()
 
 
+def test_restatement_light_shape_density_and_sampling_match_reference():
+    """Shape::pdf_value / Shape::random of whole light shapes (ShapeList.cpp:19-35, Rect.cpp:36-68,
+    Sphere.cpp:38-58, Shape.h:8-9), function by function: a flat list, one sphere, nested lists
+    with shapes of the default density, a list of 40 lights."""
+    g = util.load_golden("light_pdf")
+    for name in ("cornell", "small", "cornell_light_tree", "cornell_many_lights"):
+        scene = api.HostScene(name, 32, 32)
+        vals, dirs = restate.light_pdf(scene, g[name + "_o"], g[name + "_v"], seed=int(g["seed"]))
+        assert np.array_equal(vals, g[name + "_values"], equal_nan=True), name
+        assert np.array_equal(dirs, g[name + "_dirs"], equal_nan=True), name
+        assert (g[name + "_values"] > 0).sum() > 200, name
+
+
 def test_restatement_general_light_sampling_is_unbiased():
     """General light sampling (rects of every axis, rotated / translated / boxed lights) is an
     extension the reference cannot check: its own contract is that it leaves the expectation of
@@ -160,3 +173,12 @@ def test_reference_and_restatement_agree_on_fresh_inputs():
         a = restate.render(scene, w, h, 10, spp, seed=seed, threads=4, per_sample=True)
         b = ref.RefScene(name, w, h).render(10, spp, seed=seed, threads=4, per_sample=True)
         util.assert_samples_match(a["samples"], a["segments"], b["samples"], b["segments"], exact=True)
+
+
+@needs_ref
+def test_light_shape_golden_is_what_the_reference_returns():
+    g = util.load_golden("light_pdf")
+    for name in ("cornell", "cornell_many_lights"):
+        vals, dirs = ref.RefScene(name, 32, 32).light_pdf(g[name + "_o"], g[name + "_v"], seed=int(g["seed"]))
+        assert np.array_equal(vals, g[name + "_values"], equal_nan=True)
+        assert np.array_equal(dirs, g[name + "_dirs"], equal_nan=True)
