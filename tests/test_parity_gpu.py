@@ -443,6 +443,37 @@ def test_progressive_checkpoint_resumes_bit_identically(gpu_ctx, tmp_path):
             other.load(path)
 
 
+def _full_size_check(gpu_ctx, name, w, h, spp, with_linear_scan):
+    from oracle import restate
+
+    scene = api.HostScene(name, w, h)
+    det = lambda b, n: gpu_ctx.render(gpu_ctx.params(w, h, b, n, mode=api.RTX_MODE_DETERMINISTIC, seed=17))  # noqa: E731
+    gpu_ctx.upload(scene, api.RTX_ACCEL_BVH)
+    bvh, rays_bvh = det(0, spp)
+    lo, rays_lo = det(0, 2)
+    hi, rays_hi = det(2, spp - 2) if spp > 2 else (np.zeros_like(lo), 0)
+    assert rays_bvh == rays_lo + rays_hi
+    assert np.allclose(bvh, lo + hi, rtol=1e-5, atol=1e-6)
+    fast, rays_fast = gpu_ctx.render(gpu_ctx.params(w, h, 0, 8, mode=api.RTX_MODE_FAST, seed=17))
+    assert np.isfinite(fast).all()
+    if with_linear_scan:
+        gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+        lin, rays_lin = det(0, spp)
+        assert rays_bvh == rays_lin
+        assert np.array_equal(bvh, lin)
+    # 240x135 CPU frames of the same camera: rays per sample and mean radiance (at the same
+    # samples per pixel: clamping the pixel mean to [0, 1] is not linear in the sample count)
+    cw, ch = 240, 135
+    for img, rays_gpu, n in ((bvh, rays_bvh, spp), (fast, rays_fast, 8)):
+        means, rps = [], []
+        for seed in range(4):
+            cpu = restate.render(api.HostScene(name, cw, ch), cw, ch, 0, n, seed=seed, threads=8, bvh=not with_linear_scan)
+            means.append(float(np.clip(cpu["sum"] / n, 0, 1).mean()))
+            rps.append(cpu["rays"] / (cw * ch * n))
+        assert abs(rays_gpu / (w * h * n) / np.mean(rps) - 1) < 0.01, (name, n)
+        assert abs(float(np.clip(img / n, 0, 1).mean()) / np.mean(means) - 1) < 0.03, (name, n)
+
+
 def test_full_size_frames_through_size_independent_properties(gpu_ctx):
     """At the benchmark's frame size (1920x1080) the CPU oracle is too slow to render the frame,
     so the checks are properties that do not depend on the size: (1) the hierarchy only prunes
@@ -450,32 +481,13 @@ def test_full_size_frames_through_size_independent_properties(gpu_ctx):
     the linear scan, bit for bit, ray count included; (2) sample ranges compose: [0,5) =
     [0,2) + [2,5) with equal ray counts; (3) a low-resolution CPU render of the same scene has the
     same rays per sample and the same mean radiance up to sampling noise."""
-    from oracle import restate
+    _full_size_check(gpu_ctx, "cornell", 1920, 1080, 5, True)
+    _full_size_check(gpu_ctx, "random_field", 1920, 1080, 2, True)
 
-    w, h = 1920, 1080
-    for name, spp in (("cornell", 5), ("random_field", 2)):
-        scene = api.HostScene(name, w, h)
-        gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
-        det = lambda b, n: gpu_ctx.render(gpu_ctx.params(w, h, b, n, mode=api.RTX_MODE_DETERMINISTIC, seed=17))  # noqa: E731
-        lin, rays_lin = det(0, spp)
-        lo, rays_lo = det(0, 2)
-        hi, rays_hi = det(2, spp - 2) if spp > 2 else (np.zeros_like(lo), 0)
-        assert rays_lin == rays_lo + rays_hi
-        assert np.allclose(lin, lo + hi, rtol=1e-5, atol=1e-6)
-        gpu_ctx.upload(scene, api.RTX_ACCEL_BVH)
-        bvh, rays_bvh = det(0, spp)
-        assert rays_bvh == rays_lin
-        assert np.array_equal(bvh, lin)
-        fast, rays_fast = gpu_ctx.render(gpu_ctx.params(w, h, 0, 8, mode=api.RTX_MODE_FAST, seed=17))
-        assert np.isfinite(fast).all()
-        # 240x135 CPU frames of the same camera: rays per sample and mean radiance (at the same
-        # samples per pixel: clamping the pixel mean to [0, 1] is not linear in the sample count)
-        cw, ch = 240, 135
-        for img, rays_gpu, n in ((lin, rays_lin, spp), (fast, rays_fast, 8)):
-            means, rps = [], []
-            for seed in range(4):
-                cpu = restate.render(api.HostScene(name, cw, ch), cw, ch, 0, n, seed=seed, threads=8)
-                means.append(float(np.clip(cpu["sum"] / n, 0, 1).mean()))
-                rps.append(cpu["rays"] / (cw * ch * n))
-            assert abs(rays_gpu / (w * h * n) / np.mean(rps) - 1) < 0.01
-            assert abs(float(np.clip(img / n, 0, 1).mean()) / np.mean(means) - 1) < 0.03
+
+def test_full_size_frames_of_the_4k_and_the_100k_item_configurations(gpu_ctx):
+    """The same properties at 3840x2160 (Cornell box with extra glass / metal) and on the
+    100 000-item scene at 1920x1080; the latter without the linear scan (10^11 primitive tests per
+    sample of the frame), its CPU frames through the restatement's own hierarchy."""
+    _full_size_check(gpu_ctx, "cornell_extra", 3840, 2160, 3, True)
+    _full_size_check(gpu_ctx, "bvh_stress", 1920, 1080, 3, False)
