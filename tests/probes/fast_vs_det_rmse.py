@@ -1,10 +1,11 @@
-"""Spread of the equal-spp RMSE of fast and deterministic renders against a CPU ground truth."""
+"""Spread of the equal-spp RMSE of fast and deterministic renders against a CPU ground truth
+(a probe that uses the CPU oracle, hence kept with the tests; not collected by pytest)."""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("RTX_TEXTURE", os.path.join(ROOT, "tests", "golden", "texture_64x32.bmp"))
 from oracle import restate  # noqa: E402
