@@ -190,7 +190,8 @@ typedef struct RtxContext RtxContext;
 int rtx_create(int device, RtxContext** out_ctx);
 void rtx_destroy(RtxContext* ctx);
 const char* rtx_last_error(void);
-/* 1 if a HIP device is usable from this process, 0 otherwise (never fails). */
+/* Number of HIP devices visible to this process; 0 when there is none or the runtime cannot be
+ * initialised (never fails). */
 int rtx_device_count(void);
 
 /* Copy the scene to the GPU (and build the BVH when asked or when AUTO decides). */

@@ -100,7 +100,7 @@ int check_scene(const RtxScene* s) {
         return fail(RTX_ERR_INVALID_ARGUMENT, "RtxScene.abi_version does not match this library");
     if (s->n_prims == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "scene has no primitives");
     if (s->background_mode > RTX_BACKGROUND_SKY) return fail(RTX_ERR_INVALID_ARGUMENT, "unknown background_mode");
-    if (s->n_lights && (!s->light_kind || !s->light_a || !s->light_b || !s->light_c || !s->light_d || !s->light_e))
+    if ((s->n_lights || s->n_light_entries) && (!s->light_kind || !s->light_a || !s->light_b || !s->light_c || !s->light_d || !s->light_e))
         return fail(RTX_ERR_INVALID_ARGUMENT, "a light array is null");
     if (s->n_chains == 0 || !s->chain_begin)
         return fail(RTX_ERR_INVALID_ARGUMENT, "chain table missing (chain 0 must exist and be empty)");
@@ -603,6 +603,9 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     if (use_bvh) {
         std::string err;
         if (!rtxbvh::build(prims, groups, steps, tree, err)) return fail(RTX_ERR_TOO_LARGE, err);
+        // a lane defers at most one child per level: the stack must hold the tree's depth
+        if (tree.depth + 1 > rtxd::kBvhStackEntries)
+            return fail(RTX_ERR_TOO_LARGE, "BVH is deeper than the traversal stack");
         build_bvh_fast_items(prims, info, items, steps, fast_items, fast_maps, scan_info, scan_orig);
     }
 

@@ -149,6 +149,7 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
     const uint32_t n_all = (uint32_t)groups.size();
     items.clear();
     out.n_big = 0;
+    out.depth = 0;
     if (n_all == 0) {
         err = "no groups";
         return false;
@@ -200,6 +201,7 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
             nodes[t.node].box = bounds;
             nodes[t.node].left = t.begin;
             nodes[t.node].count = count;
+            out.depth = std::max(out.depth, t.depth);
             continue;
         }
         if (t.depth >= kMaxDepth) {

@@ -16,6 +16,7 @@ namespace rtxbvh {
 
 // Maximum tree depth the traversal stack supports (see kBvhStack in rtx_core.h).
 constexpr int kMaxDepth = 22;
+static_assert(kMaxDepth + 1 <= rtxd::kBvhStackEntries, "the traversal stack must hold one deferred child per level");
 
 // What the builder hands back.
 //   nodes   two-child nodes with 16-bit boxes on the grid `origin + q * scale` (rtxd::BvhNode),
@@ -29,6 +30,7 @@ struct Tree {
     std::vector<rtxd::BvhNode> nodes;
     std::vector<rtxd::Group> items;
     uint32_t n_big = 0;
+    int depth = 0;  // inner-node levels above the deepest leaf
     float origin[3] = {0, 0, 0};
     float scale[3] = {1, 1, 1};
 };

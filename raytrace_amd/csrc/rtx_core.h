@@ -589,7 +589,7 @@ RTX_DEV uint32_t original_prim(const SceneView& sc, uint32_t prim, bool) { retur
 #ifndef RTX_TRACE_WAVES_BVH
 #define RTX_TRACE_WAVES_BVH 4
 #endif
-constexpr int kBvhStack = 24;  // >= rtxbvh::kMaxDepth + 1: one deferred child per level
+constexpr int kBvhStack = kBvhStackEntries;  // one deferred child per level
 
 RTX_DEV bool tie_wins(uint32_t cand, bool cand_is_rect, uint32_t cur, bool cur_is_rect) {
     if (cand_is_rect && cur_is_rect) return cand > cur;

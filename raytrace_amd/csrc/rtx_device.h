@@ -152,6 +152,9 @@ struct alignas(32) BvhNode {
     uint16_t lo1[3], hi1[3];
     uint32_t child0, child1;
 };
+// Entries of the traversal's per-lane stack: one deferred child per level, so a tree may be at
+// most kBvhStackEntries - 1 levels deep (the builder bounds it, the upload checks it).
+constexpr int kBvhStackEntries = 24;
 constexpr uint32_t kBvhLeaf = 0x80000000u;
 constexpr uint32_t kBvhLeafFirst = 0x07ffffffu;
 constexpr uint32_t kBvhLeafCountShift = 27u;

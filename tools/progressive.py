@@ -94,6 +94,9 @@ def main():
             img = api.resolve_host(small.cpu().numpy(), 1)
             api.write_bmp(os.path.join(args.out, f"preview_{spp:06d}spp.bmp"), img)
     # RMSE of a Monte Carlo mean falls as spp^-1/2 until the ground truth's own noise floor
+    if not rows:  # the checkpoint already held every step
+        print(json.dumps({"summary": True, "scene": args.scene, "steps": args.steps, "steps_run": 0}), flush=True)
+        return
     first, last = rows[0], rows[-1]
     slope = np.log(last["rmse"] / first["rmse"]) / np.log(last["spp"] / first["spp"]) if len(rows) > 1 else float("nan")
     print(json.dumps({"summary": True, "scene": args.scene, "width": w, "height": h, "steps": args.steps,
