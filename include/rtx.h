@@ -210,6 +210,20 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* scene, uint32_t accel);
 int rtx_render(RtxContext* ctx, const RtxParams* params, float* accum_rgb, uint64_t* rays_out);
 
 /*
+ * rtx_render without any allocation.  No counterpart in the reference: it is for callers that
+ * cannot allocate device memory at the time of the call (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  The device-side accumulator and ray counter,
+ * which rtx_render keeps in buffers its context allocates on first use, live in one file-scope
+ * device array of the library instead (RTX_NOALLOC_MAX_PIXELS * 12 + 256 bytes, held by every
+ * GPU the process has created a context on until the process ends); the call makes no hipMalloc,
+ * hipFree or other allocating call.  Arguments and result as for rtx_render (bit-identical to
+ * it).  Frames of more than RTX_NOALLOC_MAX_PIXELS pixels are refused with RTX_ERR_TOO_LARGE.
+ * Every context on one GPU shares that GPU's array: calls that overlap on one GPU race.
+ */
+#define RTX_NOALLOC_MAX_PIXELS (1u << 21) /* 2 097 152: a 1920x1080 frame fits */
+int rtx_render_noalloc(RtxContext* ctx, const RtxParams* params, float* accum_rgb, uint64_t* rays_out);
+
+/*
  * The same frame on several GPUs from ONE process: the sample range
  * [spp_begin, spp_begin+spp_count) is cut into n_ctx contiguous blocks (the first
  * spp_count % n_ctx blocks one sample longer), block i is rendered by ctxs[i] on that

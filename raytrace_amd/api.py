@@ -97,8 +97,9 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("prim", "<i4"), ("t", "<f4"),
 RTX_SYMBOLS = (
     "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_device_count", "rtx_upload_scene",
     "rtx_render", "rtx_render_device", "rtx_render_samples", "rtx_hit", "rtx_resolve_device",
-    "rtx_scene_info", "rtx_render_multi",
+    "rtx_scene_info", "rtx_render_multi", "rtx_render_noalloc",
 )
+RTX_NOALLOC_MAX_PIXELS = 1 << 21
 RTXH_SYMBOLS = (
     "rtxh_last_error", "rtxh_scene_create", "rtxh_scene_view", "rtxh_scene_destroy",
     "rtxh_image_write", "rtxh_resolve", "rtxh_write_bmp", "rtxh_render_to_bmp",
@@ -154,6 +155,8 @@ def load_librtx() -> C.CDLL:
         lib.rtx_upload_scene.restype = C.c_int
         lib.rtx_render.argtypes = [ctxp, C.POINTER(RtxParams), C.c_void_p, C.POINTER(C.c_uint64)]
         lib.rtx_render.restype = C.c_int
+        lib.rtx_render_noalloc.argtypes = [ctxp, C.POINTER(RtxParams), C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.rtx_render_noalloc.restype = C.c_int
         lib.rtx_render_multi.argtypes = [C.POINTER(ctxp), C.c_uint32, C.POINTER(RtxParams), C.c_void_p,
                                          C.POINTER(C.c_uint64)]
         lib.rtx_render_multi.restype = C.c_int
@@ -315,6 +318,16 @@ class Context:
         assert accum.shape == (params.height, params.width, 3)
         rays = C.c_uint64(0)
         self._check(self._lib.rtx_render(self._ctx, C.byref(params), accum.ctypes.data, C.byref(rays)))
+        return accum, rays.value
+
+    def render_noalloc(self, params: RtxParams, accum: Optional[np.ndarray] = None) -> Tuple[np.ndarray, int]:
+        """rtx_render_noalloc: rtx_render over the library's static device buffer."""
+        if accum is None:
+            accum = np.zeros((params.height, params.width, 3), np.float32)
+        assert accum.dtype == np.float32 and accum.flags.c_contiguous
+        assert accum.shape == (params.height, params.width, 3)
+        rays = C.c_uint64(0)
+        self._check(self._lib.rtx_render_noalloc(self._ctx, C.byref(params), accum.ctypes.data, C.byref(rays)))
         return accum, rays.value
 
     def render_device(self, params: RtxParams, d_accum: int, d_rays: int = 0, stream: int = 0):

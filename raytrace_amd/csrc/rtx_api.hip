@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <array>
 #include <vector>
@@ -56,6 +57,32 @@ struct DeviceArray {
     }
 };
 
+// Device memory of rtx_render_noalloc: the ray counter (first 256 bytes) and the fp32 SUM frame
+// behind it.  A file-scope array, so the entry point never allocates; each GPU the process uses
+// holds its own copy until the process ends.  In host code the array's name is only a handle:
+// the address on a given GPU comes from hipGetSymbolAddress with that GPU current
+// (scratch_pointer below), and that pointer is what kernels, memsets and copies get.
+constexpr size_t kScratchCounterBytes = 256;
+constexpr size_t kScratchBytes = kScratchCounterBytes + (size_t)RTX_NOALLOC_MAX_PIXELS * 3u * sizeof(float);
+static __device__ __align__(256) __attribute__((used)) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices] = {};  // per device; written once, under g_scratch_mutex
+std::mutex g_scratch_mutex;
+
+// The scratch array's address on `device`, which must be the current device.
+hipError_t scratch_pointer(int device, void** out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 }  // namespace
 
 struct RtxContext {
@@ -90,6 +117,7 @@ struct RtxContext {
     DeviceArray<RtxHit> hits;
     DeviceArray<uint8_t> rgb8;
     DeviceArray<float> peer_frames;  // rtx_render_multi: the other contexts' partial frames, on context 0's GPU
+    void* scratch = nullptr;  // this device's copy of the file-scope scratch array (rtx_render_noalloc)
 };
 
 namespace {
@@ -434,7 +462,8 @@ int rtx_create(int device, RtxContext** out_ctx) {
         (void)hipGetLastError();
         return fail(RTX_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
     }
-    if (device < 0 || device >= n) return fail(RTX_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    if (device < 0 || device >= n || device >= kMaxDevices)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "device ordinal out of range");
     RTX_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     RTX_HIP(hipGetDeviceProperties(&prop, device));
@@ -444,6 +473,11 @@ int rtx_create(int device, RtxContext** out_ctx) {
     RtxContext* ctx = new (std::nothrow) RtxContext();
     if (!ctx) return fail(RTX_ERR_HIP, "out of host memory");
     ctx->device = device;
+    hipError_t e = scratch_pointer(device, &ctx->scratch);  // once per device, with that device current
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(RTX_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+    }
     *out_ctx = ctx;
     return RTX_OK;
 }
@@ -720,6 +754,36 @@ int rtx_render(RtxContext* ctx, const RtxParams* params, float* accum_rgb, uint6
     if (rays_out) {
         unsigned long long r = 0;
         RTX_HIP(hipMemcpy(&r, ctx->rays.ptr, sizeof r, hipMemcpyDeviceToHost));
+        *rays_out = r;
+    }
+    return RTX_OK;
+}
+
+int rtx_render_noalloc(RtxContext* ctx, const RtxParams* params, float* accum_rgb, uint64_t* rays_out) {
+    int rc = check_params(ctx, params);
+    if (rc != RTX_OK) return rc;
+    if (!accum_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "accumulator is null");
+    const uint64_t n_pixels = (uint64_t)params->width * params->height;
+    if (n_pixels > RTX_NOALLOC_MAX_PIXELS)
+        return fail(RTX_ERR_TOO_LARGE, "rtx_render_noalloc: the frame has " + std::to_string(n_pixels) +
+                                           " pixels, the static device buffer holds " +
+                                           std::to_string(RTX_NOALLOC_MAX_PIXELS) + " (use rtx_render)");
+    RTX_HIP(hipSetDevice(ctx->device));
+    unsigned char* base = static_cast<unsigned char*>(ctx->scratch);
+    unsigned long long* d_rays = reinterpret_cast<unsigned long long*>(base);
+    float* d_accum = reinterpret_cast<float*>(base + kScratchCounterBytes);
+    const size_t bytes = (size_t)n_pixels * 3u * sizeof(float);
+    // the array keeps what the last call on this GPU left: the counter starts at zero, the frame
+    // is either overwritten by the kernel (accumulate == 0) or replaced by the caller's
+    RTX_HIP(hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), nullptr));
+    if (params->accumulate) RTX_HIP(hipMemcpy(d_accum, accum_rgb, bytes, hipMemcpyHostToDevice));
+    rc = rtx_render_device(ctx, params, d_accum, d_rays, nullptr);
+    if (rc != RTX_OK) return rc;
+    RTX_HIP(hipStreamSynchronize(nullptr));
+    RTX_HIP(hipMemcpy(accum_rgb, d_accum, bytes, hipMemcpyDeviceToHost));
+    if (rays_out) {
+        unsigned long long r = 0;
+        RTX_HIP(hipMemcpy(&r, d_rays, sizeof r, hipMemcpyDeviceToHost));
         *rays_out = r;
     }
     return RTX_OK;
