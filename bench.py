@@ -16,6 +16,11 @@ sample index, so the image does not depend on N beyond fp32 summation order.
 The scene is resident in HBM before the timed region; the accumulator never
 leaves the device inside it (only the 8-bit resolve is copied to the host).
 
+`--gpus N` with N > 1 and no launcher (no WORLD_SIZE in the environment) starts the N ranks
+itself, as child processes, and forwards rank 0's line; under torchrun (`python -m
+torch.distributed.run --nproc-per-node N bench.py --gpus N`) it is one of the ranks.
+`--single-process` drives all N GPUs from one process through rtx_render_multi instead.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -124,20 +129,160 @@ def cpu_baseline(scene: str, w: int, h: int, threads: int, seconds_budget: float
     return out
 
 
-def main() -> int:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cornell_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--spp-per-step", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0, help="override the workload's frame width (tests)")
+    ap.add_argument("--height", type=int, default=0, help="override the workload's frame height (tests)")
     ap.add_argument("--mode", default="fast", choices=["fast", "deterministic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true",
                     help="reduce / resolve on the render stream (no overlap): per-kernel counters then see the "
                          "trace kernel alone")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    args = ap.parse_args()
+    ap.add_argument("--single-process", action="store_true",
+                    help="one process drives all --gpus devices through rtx_render_multi (the C ABI's own split: "
+                         "peer copies to device 0, ordered adds) instead of one process per GPU with RCCL")
+    ap.add_argument("--share-device", action="store_true",
+                    help="with --single-process: put every context on device 0 when fewer than --gpus devices "
+                         "are visible (functional rehearsal on a one-GPU box; the number is not a scaling result)")
+    ap.add_argument("--engine", default="",
+                    help="test hook: dotted module name providing make_engine(scene, width, height, mode) -> object "
+                         "with render(begin, count) -> (fp32 SUM frame as a CPU torch tensor, rays); the ranks then "
+                         "use CPU tensors and the gloo backend, everything else (launch, sample split, pipelined "
+                         "reduce, resolve, JSON line) is the code the GPU run uses")
+    ap.add_argument("--dump-frame", default="", help="rank 0 saves the final fp32 SUM frame to this .npy file (tests)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args) -> int:
+    """`--gpus N` without a launcher: start N ranks of this script (fresh child processes, one per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), forward rank 0's JSON
+    line and fail if any rank fails.  Runs before anything in this process has touched the GPU and
+    never execs: the children are started with subprocess."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    if not args.engine:
+        import torch  # device_count() does not initialise the GPU
+
+        visible = torch.cuda.device_count()
+        if visible < n:
+            print(f"bench.py: --gpus {n} but only {visible} GPU(s) visible", file=sys.stderr)
+            return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    deadline = time.time() + 120.0
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(p.wait())
+    # rank 0's JSON line goes to stdout; anything else a library printed there (gloo and RCCL
+    # announce themselves on stdout) goes to stderr, so that stdout stays the one line
+    for line in out.decode(errors="replace").splitlines():
+        print(line, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr, flush=True)
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def trace_kernel_name(mode: str, bvh: bool) -> str:
+    # fast-mode BVH frames run the kernel that decouples traversal from shading
+    return "trace_bvh_kernel" if (bvh and mode == "fast") else "trace_kernel"
+
+
+def run_single_process(args) -> int:
+    """All GPUs from one process through rtx_render_multi (host accumulator: the PCIe copy of the
+    frame is inside the timed region, unlike the per-rank path)."""
+    import torch  # noqa: F401  (its HIP runtime must be the one in the process)
+
+    from raytrace_amd import api
+
+    n = args.gpus
+    visible = api.device_count()
+    if visible < 1:
+        raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
+    if visible < n and not args.share_device:
+        raise SystemExit(f"--gpus {n} but only {visible} GPU(s) visible (--share-device rehearses on one)")
+    scene_name, w, h, spp_default = WORKLOADS[args.workload]
+    w, h = args.width or w, args.height or h
+    spp = args.spp_per_step or spp_default
+    mode = api.RTX_MODE_FAST if args.mode == "fast" else api.RTX_MODE_DETERMINISTIC
+    devices = [d if d < visible else 0 for d in range(n)]
+    scene = api.HostScene(scene_name, w, h)
+    ctxs = [api.Context(d) for d in devices]
+    for c in ctxs:
+        c.upload(scene, api.RTX_ACCEL_AUTO)
+    info = ctxs[0].info()
+    frame = np.zeros((h, w, 3), np.float32)
+
+    def step(k):
+        p = ctxs[0].params(w, h, k * n * spp, n * spp, mode=mode, seed=0, accumulate=True)
+        return api.render_multi(ctxs, p, frame)[1]
+
+    for k in range(args.warmup):
+        step(k)
+    frame[:] = 0
+    t0 = time.perf_counter()
+    n_rays = sum(step(args.warmup + k) for k in range(args.steps))
+    elapsed = time.perf_counter() - t0
+    image = api.resolve_host(frame, n * spp * args.steps)
+    samples = w * h * spp * n * args.steps
+    print(json.dumps({
+        "metric": "Mrays/s at 1080p Cornell box (whole job)" if args.workload == "cornell_1080p"
+                  else f"Mrays/s ({args.workload})",
+        "value": n_rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "scene": scene_name, "width": w, "height": h,
+                   "spp_per_step_per_gpu": spp, "spp_total": spp * n * args.steps, "max_depth": 50, "mode": args.mode,
+                   "accel": "bvh" if info.accel == api.RTX_ACCEL_BVH else "linear", "devices": devices,
+                   "parallelism": f"one process, rtx_render_multi over {n} contexts: spp-split, peer copies to "
+                                  "device 0, ordered adds; the frame returns to the host every step (PCIe inside "
+                                  "the timed region)"},
+        "spp_per_s": spp * n * args.steps / elapsed, "rays_per_sample": n_rays / samples,
+        "image_mean_rgb8": float(image.mean()),
+    }), flush=True)
+    for c in ctxs:
+        c.close()
+    return 0
+
+
+def main() -> int:
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.single_process:
+        return run_single_process(args)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return launch_ranks(args)  # before any torch.cuda / HIP call in this process
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py with --gpus equal to the "
+                         "number of ranks (or without a launcher: it starts its own ranks)")
 
     import torch
     import torch.distributed as dist
@@ -145,41 +290,63 @@ def main() -> int:
     from raytrace_amd import api
     from raytrace_amd.distributed import run_pipelined_steps, step_sample_range
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-
     scene_name, w, h, spp_default = WORKLOADS[args.workload]
+    w, h = args.width or w, args.height or h
     spp = args.spp_per_step or spp_default
     mode = api.RTX_MODE_FAST if args.mode == "fast" else api.RTX_MODE_DETERMINISTIC
 
-    ctx = api.Context(local_rank)
-    scene = api.HostScene(scene_name, w, h)
-    ctx.upload(scene, api.RTX_ACCEL_AUTO)
-    info = ctx.info()
+    engine = None
+    if args.engine:  # test hook: CPU tensors + gloo around an engine the test supplies
+        import importlib
+
+        engine = importlib.import_module(args.engine).make_engine(scene_name, w, h, args.mode)
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        ctx, bvh = None, False
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
+        ctx = api.Context(local_rank)
+        scene = api.HostScene(scene_name, w, h)
+        ctx.upload(scene, api.RTX_ACCEL_AUTO)
+        bvh = ctx.info().accel == api.RTX_ACCEL_BVH
+
+    def sync():
+        if engine is None:
+            torch.cuda.synchronize(dev)
 
     step_accum = [torch.zeros((h, w, 3), dtype=torch.float32, device=dev) for _ in range(2)]  # this GPU's steps
     frame_accum = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)  # rank 0: running frame
     rays = torch.zeros(1, dtype=torch.int64, device=dev)
-    render_stream = torch.cuda.current_stream(dev)
-    # reduce + resolve of step k while step k+1 renders
-    side_stream = render_stream if args.serial else torch.cuda.Stream(dev)
+    if engine is None:
+        render_stream = torch.cuda.current_stream(dev)
+        # reduce + resolve of step k while step k+1 renders
+        side_stream = render_stream if args.serial else torch.cuda.Stream(dev)
+    else:
+        render_stream = side_stream = None
     ev = {}
 
     total_spp_done = 0
 
     def render(k: int, buf):
         begin, _ = step_sample_range(k, rank, world, spp)
-        p = ctx.params(w, h, begin, spp, mode=mode, seed=0, accumulate=False)
         timed = k >= args.warmup
+        if engine is not None:
+            t = time.perf_counter()
+            part, n = engine.render(begin, spp)
+            buf.copy_(part)
+            rays.add_(int(n))
+            if timed:
+                ev[k] = (time.perf_counter() - t) * 1e3
+            return
+        p = ctx.params(w, h, begin, spp, mode=mode, seed=0, accumulate=False)
         if timed:
             ev[k] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[k][0].record(render_stream)  # on the stream the kernel is launched on
@@ -194,20 +361,24 @@ def main() -> int:
         total_spp_done += spp * world
         if rank == 0:
             frame_accum.add_(buf)
+            if engine is not None:
+                return api.resolve_host(frame_accum.numpy(), total_spp_done)
             return ctx.resolve_device(w, h, total_spp_done, frame_accum.data_ptr(), side_stream.cuda_stream)
         return None
 
     run_pipelined_steps(range(args.warmup), render, combine, step_accum, render_stream, side_stream)
-    torch.cuda.synchronize(dev)
+    sync()
     rays.zero_()
+    frame_accum.zero_()  # the reported frame holds the timed steps' samples only
+    total_spp_done = 0
 
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     images = run_pipelined_steps(range(args.warmup, args.warmup + args.steps), render, combine, step_accum,
                                  render_stream, side_stream)
-    torch.cuda.synchronize(dev)
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -221,11 +392,13 @@ def main() -> int:
     elapsed = float(el.item())
     n_rays = int(rays_total.item())
     my_rays = int(rays.item())
-    kernel_ms = [a.elapsed_time(b) for a, b in ev.values()]
+    kernel_ms = [v if engine is not None else v[0].elapsed_time(v[1]) for v in ev.values()]
 
     if rank == 0:
+        if args.dump_frame:
+            np.save(args.dump_frame, frame_accum.cpu().numpy())
         samples = w * h * spp * world * args.steps
-        flops_per_ray, flops_src = load_flops_per_ray(scene_name, info.accel == api.RTX_ACCEL_BVH)
+        flops_per_ray, flops_src = load_flops_per_ray(scene_name, bvh)
         avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
         rays_per_launch = my_rays / args.steps
         achieved_tflops = None if flops_per_ray is None else flops_per_ray * rays_per_launch / avg_kernel_s / 1e12
@@ -239,7 +412,7 @@ def main() -> int:
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak",  # every GPU renders spp_per_step_per_gpu samples of the whole frame per step
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -251,7 +424,7 @@ def main() -> int:
                 "spp_total": spp * world * args.steps,
                 "max_depth": 50,
                 "mode": args.mode,
-                "accel": "bvh" if info.accel == api.RTX_ACCEL_BVH else "linear",
+                "accel": "bvh" if bvh else "linear",
                 "parallelism": f"spp-split x{world}, reduce(sum) of fp32 accumulators to rank 0 per step, "
                                "overlapped with the next step's rendering",
             },
@@ -266,7 +439,7 @@ def main() -> int:
                 "frac": None if achieved_tflops is None else achieved_tflops / PEAK_FP32_VALU_TFLOPS,
                 "traffic": load_hbm_traffic(args.workload, spp),
                 "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/hbm_traffic.json)",
-                "kernel": "trace_kernel",
+                "kernel": trace_kernel_name(args.mode, bvh) if engine is None else args.engine,
                 "kernel_ms_avg": float(np.mean(kernel_ms)),
                 "kernel_ms_min": float(np.min(kernel_ms)),
                 "rays_per_launch": rays_per_launch,
@@ -276,15 +449,20 @@ def main() -> int:
             },
             "image_mean_rgb8": float(image.mean()) if image is not None else None,
         }
-        if not args.no_cpu_baseline and world == 1:
-            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        if engine is not None:
+            out["engine"] = args.engine
+        if not args.no_cpu_baseline and world == 1 and engine is None:
+            host_cores = os.cpu_count() or 1
+            threads = args.cpu_threads or min(16, host_cores)
             try:
                 out["cpu_baseline"] = cpu_baseline(scene_name, w, h, threads)
+                out["cpu_baseline"]["host_cores_visible"] = host_cores
             except Exception as e:  # the oracle is optional equipment, the GPU numbers are not
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     return 0
 
