@@ -117,6 +117,7 @@ struct RtxContext {
     DeviceArray<RtxHit> hits;
     DeviceArray<uint8_t> rgb8;
     DeviceArray<float> peer_frames;  // rtx_render_multi: the other contexts' partial frames, on context 0's GPU
+    uint64_t scene_hash = 0;  // of everything rtx_upload_scene was given (rtx_render_multi compares it)
     void* scratch = nullptr;  // this device's copy of the file-scope scratch array (rtx_render_noalloc)
 };
 
@@ -409,6 +410,50 @@ void build_bvh_fast_items(const std::vector<rtxd::Prim>& prims, const std::vecto
         }
         out.push_back(I);
     }
+}
+
+// FNV-1a over the bytes of the caller's scene: contexts that are to render one frame together
+// must have been given the same arrays.
+struct SceneHasher {
+    uint64_t h = 1469598103934665603ull;
+    void bytes(const void* p, size_t n) {
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    }
+    template <typename T>
+    void array(const T* p, size_t n) {
+        const uint64_t tag = n;
+        bytes(&tag, sizeof tag);
+        if (p && n) bytes(p, n * sizeof(T));
+    }
+};
+uint64_t hash_scene(const RtxScene* s, bool use_bvh) {
+    SceneHasher H;
+    const uint32_t n_le = s->n_light_entries ? s->n_light_entries : s->n_lights;
+    const uint32_t head[] = {s->n_prims, s->n_chains, s->n_steps, s->n_materials, s->n_textures, s->n_lights,
+                             s->light_is_list, n_le, s->light_sampling, s->background_mode, use_bvh ? 1u : 0u};
+    H.array(head, sizeof head / sizeof head[0]);
+    H.array(s->prim_kind, s->n_prims); H.array(s->prim_flip, s->n_prims); H.array(s->prim_material, s->n_prims);
+    H.array(s->prim_chain, s->n_prims);
+    H.array(s->prim_a, s->n_prims); H.array(s->prim_b, s->n_prims); H.array(s->prim_c, s->n_prims);
+    H.array(s->prim_d, s->n_prims); H.array(s->prim_e, s->n_prims);
+    H.array(s->chain_begin, (size_t)s->n_chains + 1u);
+    H.array(s->step_kind, s->n_steps);
+    H.array(s->step_x, s->n_steps); H.array(s->step_y, s->n_steps); H.array(s->step_z, s->n_steps);
+    H.array(s->step_w, s->n_steps);
+    H.array(s->mat_kind, s->n_materials); H.array(s->mat_texture, s->n_materials); H.array(s->mat_param, s->n_materials);
+    H.array(s->tex_kind, s->n_textures);
+    H.array(s->tex_r, s->n_textures); H.array(s->tex_g, s->n_textures); H.array(s->tex_b, s->n_textures);
+    H.array(s->tex_odd, s->n_textures); H.array(s->tex_even, s->n_textures); H.array(s->tex_offset, s->n_textures);
+    H.array(s->texels, (size_t)s->n_texel_bytes);
+    H.array(s->light_kind, n_le);
+    H.array(s->light_a, n_le); H.array(s->light_b, n_le); H.array(s->light_c, n_le); H.array(s->light_d, n_le);
+    H.array(s->light_e, n_le);
+    H.array(s->light_first, s->light_first ? n_le : 0u); H.array(s->light_count, s->light_count ? n_le : 0u);
+    H.array(s->light_chain, s->light_chain ? n_le : 0u);
+    H.array(s->cam_origin, 3); H.array(s->cam_ll, 3); H.array(s->cam_u, 3); H.array(s->cam_v, 3);
+    H.array(s->background, 3);
+    return H.h;
 }
 
 int check_params(const RtxContext* ctx, const RtxParams* p) {
@@ -710,6 +755,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     ctx->info.n_items = (uint32_t)groups.size();
     ctx->info.n_bvh_nodes = (uint32_t)nodes.size();
     ctx->info.accel = use_bvh ? RTX_ACCEL_BVH : RTX_ACCEL_LINEAR;
+    ctx->scene_hash = hash_scene(s, use_bvh);
     ctx->has_scene = true;
     return RTX_OK;
 }
@@ -812,7 +858,7 @@ int rtx_render_multi(RtxContext* const* ctxs, uint32_t n_ctx, const RtxParams* p
             if (ctxs[k] == ctxs[i]) return fail(RTX_ERR_INVALID_ARGUMENT, "the same context is listed twice");
         int rc = check_params(ctxs[i], params);
         if (rc != RTX_OK) return rc;
-        if (ctxs[i]->info.n_prims != ctxs[0]->info.n_prims || ctxs[i]->info.accel != ctxs[0]->info.accel)
+        if (ctxs[i]->scene_hash != ctxs[0]->scene_hash)
             return fail(RTX_ERR_INVALID_ARGUMENT, "the contexts do not hold the same scene");
     }
     RtxContext* root = ctxs[0];
@@ -827,9 +873,12 @@ int rtx_render_multi(RtxContext* const* ctxs, uint32_t n_ctx, const RtxParams* p
         RTX_HIP(hipMemset(ctxs[i]->rays.ptr, 0, sizeof(unsigned long long)));
         if (ctxs[i]->device != root->device) {
             int can = 0;  // direct xGMI / PCIe peer writes where the platform has them; else the copy is staged by the runtime
-            if (hipDeviceCanAccessPeer(&can, ctxs[i]->device, root->device) == hipSuccess && can)
-                (void)hipDeviceEnablePeerAccess(root->device, 0);
-            (void)hipGetLastError();  // "already enabled" is not an error here
+            if (hipDeviceCanAccessPeer(&can, ctxs[i]->device, root->device) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    return fail(RTX_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+            }
+            (void)hipGetLastError();  // "already enabled" / "no peer access" leave a sticky code behind
         }
     }
     RTX_HIP(hipSetDevice(root->device));

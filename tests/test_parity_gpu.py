@@ -256,9 +256,36 @@ def test_render_multi_splits_the_sample_range_and_sums_in_context_order(gpu_ctx)
             api.render_multi([gpu_ctx, gpu_ctx], p)  # the same context twice
         with pytest.raises(api.RtxError):
             api.render_multi([gpu_ctx, api.Context(0)], p)  # a context without a scene
+        # another scene with the same primitive count and accelerator (here: another camera)
+        others[0].upload(api.HostScene("cornell_extra", w + 1, h), api.RTX_ACCEL_LINEAR)
+        with pytest.raises(api.RtxError) as e:
+            api.render_multi(group, p)
+        assert "same scene" in str(e.value)
     finally:
         for c in others:
             c.close()
+
+
+def test_render_multi_across_two_devices(gpu_ctx):
+    """The cross-device leg of rtx_render_multi (peer access, hipMemcpyPeerAsync between GPUs, the
+    root's stream waiting on another device's event): needs a second GPU."""
+    if api.device_count() < 2:
+        pytest.skip("one GPU visible: the cross-device copies of rtx_render_multi need two")
+    w, h = 83, 47
+    scene = api.HostScene("cornell_extra", w, h)
+    gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+    other = api.Context(1)
+    try:
+        other.upload(scene, api.RTX_ACCEL_LINEAR)
+        for mode in (api.RTX_MODE_DETERMINISTIC, api.RTX_MODE_FAST):
+            p = gpu_ctx.params(w, h, 3, 9, mode=mode, seed=3)  # blocks of 5 and 4 samples
+            a, ra = gpu_ctx.render(gpu_ctx.params(w, h, 3, 5, mode=mode, seed=3))
+            b, rb = gpu_ctx.render(gpu_ctx.params(w, h, 8, 4, mode=mode, seed=3))
+            got, rays = api.render_multi([gpu_ctx, other], p)
+            assert rays == ra + rb
+            assert np.array_equal(got, a + b)
+    finally:
+        other.close()
 
 
 def test_edge_cases(gpu_ctx):
