@@ -1624,7 +1624,7 @@ constexpr uint32_t kLeafBatch = RTX_LEAF_BATCH;
 #define RTX_BVH_WAVES 6  // minimum resident waves per SIMD the kernel is compiled for (80 VGPRs, none spilled; 5: 82)
 #endif
 
-template <bool kLightTree>
+template <bool kLightTree, bool kSamples>
 __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel(const TraceArgs a) {
     __shared__ float s_acc[RTX_BVH_BLOCK / 64][3][64];
     __shared__ uint32_t s_stack[kBvhStack][RTX_BVH_BLOCK];
@@ -1689,6 +1689,14 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     atomicAdd(&s_acc[wave][1][slot], L.y);
                     atomicAdd(&s_acc[wave][2][slot], L.z);
                     rays += segs;
+                    if (kSamples) {  // per-sample outputs, as trace_kernel writes them
+                        const uint32_t i = x0 + (slot & (tile_w - 1u)), j = y0 + (slot >> twl);
+                        size_t k = (size_t)(j * a.width + i) * a.spp_count + (item >> pixl);
+                        a.sample_rgb[3 * k + 0] = L.x;
+                        a.sample_rgb[3 * k + 1] = L.y;
+                        a.sample_rgb[3 * k + 2] = L.z;
+                        if (a.sample_segments) a.sample_segments[k] = segs;
+                    }
                     phase = kIdle;
                 } else {
                     phase = kNewRay;

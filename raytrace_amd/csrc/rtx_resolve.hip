@@ -2,7 +2,7 @@
 // c /= ns (Scene.cpp:150), DenanFilter (DenanFilter.h:8-13), GammaFilter
 // (GammaFilter.h:7-9 -> Util.h:41-47, powf(c, 1/2.2)), TonemapFilter
 // (TonemapFilter.h:8-10, clamp to [0,1]), then c * 255.99f truncated to 8 bits
-// (Image.h:36-38).
+// (Image.h:36-38) - byte for byte the reference's output.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -12,31 +12,42 @@
 
 namespace rtx_post {
 
-__device__ __forceinline__ float clamp01(float c) {
-    // maxPerElem(c, 0) then minPerElem(., 1) (vec_aos.h:418-442): a NaN compares false
-    // and yields 0
-    float m = (c > 0.0f) ? c : 0.0f;
-    return (m < 1.0f) ? m : 1.0f;
+// The chain gamma -> clamp -> * 255.99f truncated is a monotone step function of its fp32 input,
+// so 255 thresholds describe it completely: kThreshold[k] is the smallest value whose code is
+// >= k under the reference's own chain and libm powf (generated from the reference and checked
+// against it on every float in [0, 1]; tests/golden/make_golden.py).  Searching the table gives
+// the reference's bytes exactly, which no device powf does.  Negative inputs and -0 get code 0
+// (powf of a negative finite base is NaN, which the clamp turns into 0; vec_aos.h:418-442),
+// except -inf: powf(-inf, 1/2.2) is +inf, code 255.
+__constant__ uint32_t kThresholdBits[256] = {
+#include "rtx_resolve_table.inc"
+};
+
+__device__ __forceinline__ uint32_t code_of(float c, const float* table) {
+    c = (c == -__builtin_inff()) ? __builtin_inff() : c;
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t step = 128u; step != 0u; step >>= 1) k += (c >= table[k + step]) ? step : 0u;
+    return k;
 }
 
 __global__ void __launch_bounds__(256) resolve_kernel(const float* __restrict__ accum,
                                                       uint8_t* __restrict__ rgb8, uint32_t n_pixels,
                                                       float ns) {
+    __shared__ float s_table[256];
+    s_table[threadIdx.x] = __uint_as_float(kThresholdBits[threadIdx.x]);
+    __syncthreads();
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_pixels) return;
-    float r = accum[3u * k + 0u] / ns;
-    float g = accum[3u * k + 1u] / ns;
-    float b = accum[3u * k + 2u] / ns;
-    r = !(r == r) ? 1.0f : r;
+    float r = __fdiv_rn(accum[3u * k + 0u], ns);  // c /= ns: three IEEE divides (Scene.cpp:150)
+    float g = __fdiv_rn(accum[3u * k + 1u], ns);
+    float b = __fdiv_rn(accum[3u * k + 2u], ns);
+    r = !(r == r) ? 1.0f : r;  // DenanFilter.h:8-13
     g = !(g == g) ? 0.0f : g;
     b = !(b == b) ? 1.0f : b;
-    const float inv_gamma = 1.0f / 2.2f;
-    r = clamp01(powf(r, inv_gamma));
-    g = clamp01(powf(g, inv_gamma));
-    b = clamp01(powf(b, inv_gamma));
-    rgb8[3u * k + 0u] = (uint8_t)(r * 255.99f);
-    rgb8[3u * k + 1u] = (uint8_t)(g * 255.99f);
-    rgb8[3u * k + 2u] = (uint8_t)(b * 255.99f);
+    rgb8[3u * k + 0u] = (uint8_t)code_of(r, s_table);
+    rgb8[3u * k + 1u] = (uint8_t)code_of(g, s_table);
+    rgb8[3u * k + 2u] = (uint8_t)code_of(b, s_table);
 }
 
 __global__ void __launch_bounds__(256) add_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {

@@ -5,7 +5,7 @@ oracle/Makefile, fed the counter-based stream of include/rtx_det.h).
 
 Run from the repository root in a container that holds /root/reference:
     make -C oracle && python tests/golden/make_golden.py [section ...]
-(sections: texture samples hits misc pieces flops gt; default all; "samples:textured" and
+(sections: texture samples hits misc pieces lights flops gt resolve; default all but "resolve_exhaustive"; "samples:textured" and
 "hits:textured" restrict a section to one scene).
 The reference has no fixtures of its own for this path, so these files are what pins
 the CPU restatement (and through it the GPU path) wherever the reference is absent.
@@ -136,6 +136,8 @@ def main(argv):
         flops_per_ray()
     if want("gt"):
         ground_truth()
+    if want("resolve") or want("resolve_exhaustive"):
+        resolve_thresholds(exhaustive=want("resolve_exhaustive"))
 
 
 LIGHT_SCENES = ("cornell", "small", "cornell_light_tree", "cornell_many_lights")
@@ -239,6 +241,63 @@ def ground_truth():
     np.savez_compressed(os.path.join(HERE, "ground_truth_cornell_160x90.npz"), mean=gt.astype(np.float32),
                         spp=np.int32(spp))
     print("ground truth done", gt.mean())
+
+
+def _codes(bits):
+    """8-bit code the reference's Image::write gives the float with these bits (green channel:
+    no NaN substitution can interfere, DenanFilter.h:11)."""
+    x = np.zeros((bits.size, 3), np.float32)
+    x[:, 1] = bits.astype(np.uint32).view(np.float32)
+    return ref.image_write(x)[:, 1].astype(np.int64)
+
+
+def resolve_thresholds(exhaustive=False):
+    """Image::write (Image.h:30-39: gamma powf, Util.h:41-47; clamp; * 255.99f truncated) is a
+    monotone step function of a non-negative fp32 input, so it is fully described by 255
+    thresholds: T[k] = the smallest fp32 c with code(c) >= k.  Found by bisection over the bit
+    patterns of the non-negative floats (their order is the order of their bits) with the
+    reference's own filter chain and libm; the device resolve searches this table instead of
+    calling a powf of its own.  `exhaustive` re-evaluates the reference on EVERY float in
+    [0, 1] and checks it against the table (about two minutes)."""
+    top = np.uint64(0x7f800000)  # +inf
+    lo = np.zeros(256, np.uint64)             # code(lo) < k   (bits 0 = +0.0 has code 0)
+    hi = np.full(256, top, np.uint64)         # code(hi) >= k  (+inf has code 255)
+    ks = np.arange(256)
+    assert _codes(np.array([0], np.uint32))[0] == 0 and _codes(np.array([top], np.uint32))[0] == 255
+    for _ in range(33):
+        mid = (lo + hi) // 2
+        c = _codes(mid.astype(np.uint32))
+        ge = c >= ks
+        hi = np.where(ge & (mid > lo), mid, hi)
+        lo = np.where(~ge, mid, lo)
+    assert (hi - lo <= 1).all()
+    T = hi.astype(np.uint32)
+    T[0] = 0
+    # the step really is at T[k]: code(T[k]) >= k > code(previous float)
+    assert (_codes(T[1:]) >= ks[1:]).all() and (_codes(T[1:] - 1) < ks[1:]).all()
+    assert (np.diff(T[1:].astype(np.int64)) > 0).all()
+    checked = 0
+    if exhaustive:
+        chunk = 1 << 24
+        edges = T[1:].view(np.float32)
+        for begin in range(0, 0x3f800000 + chunk, chunk):
+            bits = np.arange(begin, min(begin + chunk, 0x3f800001), dtype=np.uint32)
+            if bits.size == 0:
+                break
+            want = np.searchsorted(edges, bits.view(np.float32), side="right")
+            assert np.array_equal(_codes(bits), want), hex(begin)
+            checked += bits.size
+        print("resolve: every float in [0, 1] checked:", checked)
+    np.savez_compressed(os.path.join(HERE, "resolve_thresholds.npz"), threshold_bits=T,
+                        exhaustive_floats_checked=np.uint64(checked))
+    inc = os.path.join(ROOT, "raytrace_amd", "csrc", "rtx_resolve_table.inc")
+    with open(inc, "w") as f:
+        f.write("// Generated by tests/golden/make_golden.py (section \"resolve\") from the reference's own\n"
+                "// Image::write chain (Image.h:30-39, Util.h:41-47) and the libm it runs on: entry k is the bit\n"
+                "// pattern of the smallest fp32 value whose 8-bit code is >= k (entry 0 is unused).\n")
+        for k in range(0, 256, 8):
+            f.write("    " + ", ".join(f"0x{int(v):08x}u" for v in T[k:k + 8]) + ",\n")
+    print("resolve thresholds written", T[1], T[128], T[255])
 
 
 if __name__ == "__main__":

@@ -182,3 +182,41 @@ def test_light_shape_golden_is_what_the_reference_returns():
         vals, dirs = ref.RefScene(name, 32, 32).light_pdf(g[name + "_o"], g[name + "_v"], seed=int(g["seed"]))
         assert np.array_equal(vals, g[name + "_values"], equal_nan=True)
         assert np.array_equal(dirs, g[name + "_dirs"], equal_nan=True)
+
+
+def test_resolve_threshold_table_is_the_references_byte_staircase():
+    """The 255 thresholds the device resolve searches (generated from the reference's Image::write,
+    exhaustively checked on [0, 1] when generated): the compiled-in table is the fixture, and
+    the fixture reproduces the reference's bytes - the committed Image::write table, and live
+    through the reference / the host filter chain on random values and on every threshold's
+    neighbours."""
+    import os
+    import re
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = util.load_golden("resolve_thresholds")
+    T = g["threshold_bits"].astype(np.uint32)
+    assert int(g["exhaustive_floats_checked"]) == 0x3f800001  # every float in [0, 1]
+    inc = open(os.path.join(ROOT, "raytrace_amd", "csrc", "rtx_resolve_table.inc")).read()
+    compiled = np.array([int(v, 16) for v in re.findall(r"0x([0-9a-f]{8})u", inc)], np.uint32)
+    assert np.array_equal(compiled, T)
+    edges = T[1:].view(np.float32)
+
+    def staircase(x):
+        x = np.asarray(x, np.float32)
+        r = np.where(np.isnan(x[:, 0]), np.float32(1), x[:, 0])  # DenanFilter.h:8-13
+        gch = np.where(np.isnan(x[:, 1]), np.float32(0), x[:, 1])
+        b = np.where(np.isnan(x[:, 2]), np.float32(1), x[:, 2])
+        # (powf(-inf, 1/2.2) is +inf: the one negative input whose code is not 0)
+        return np.stack([np.searchsorted(edges, np.where(np.isneginf(c), np.float32(np.inf), c), side="right")
+                         for c in (r, gch, b)], 1).astype(np.uint8)
+
+    iw = util.load_golden("image_write")
+    assert np.array_equal(staircase(iw["rgb"]), iw["rgb8"])
+    rng = np.random.default_rng(8)
+    x = np.concatenate([rng.random((20000, 3)).astype(np.float32) ** 3,
+                        np.repeat(np.concatenate([T[1:] - 1, T[1:], T[1:] + 1]).astype(np.uint32).view(np.float32)[:, None], 3, 1),
+                        rng.normal(0, 2, (2000, 3)).astype(np.float32)])
+    assert np.array_equal(staircase(x), api.image_write(x))  # the product's host chain
+    if ref.available():
+        assert np.array_equal(staircase(x), ref.image_write(x))
