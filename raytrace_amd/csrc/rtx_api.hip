@@ -107,6 +107,8 @@ struct RtxContext {
     DeviceArray<rtxd::BvhMap> bvh_maps;
     DeviceArray<uint32_t> scan_orig;
     DeviceArray<rtxd::BvhNode> bvh;
+    DeviceArray<rtxd::WideNode> bvh_wide;
+    DeviceArray<rtxd::BvhFastItem> wide_items;
     DeviceArray<rtxd::Group> bvh_items;
     // scratch owned by the host-buffer entry points
     DeviceArray<float> accum;
@@ -679,6 +681,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     std::vector<rtxd::Group>& items = tree.items;  // leaf order, then the items outside the tree
     std::vector<rtxd::BvhFastItem> fast_items;
     std::vector<rtxd::BvhMap> fast_maps;
+    std::vector<rtxd::BvhFastItem> wide_items;
     if (use_bvh) {
         std::string err;
         if (!rtxbvh::build(prims, groups, steps, tree, err)) return fail(RTX_ERR_TOO_LARGE, err);
@@ -686,6 +689,14 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
         if (tree.depth + 1 > rtxd::kBvhStackEntries)
             return fail(RTX_ERR_TOO_LARGE, "BVH is deeper than the traversal stack");
         build_bvh_fast_items(prims, info, items, steps, fast_items, fast_maps, scan_info, scan_orig);
+        // the eight-wide tree of the fast trace kernel reads the leaf records in its own order; a
+        // tree deeper than that kernel's stack is rendered through the two-child tree instead
+        if (tree.wide_depth <= rtxd::kWideStackEntries) {
+            wide_items.reserve(tree.wide_order.size());
+            for (uint32_t k : tree.wide_order) wide_items.push_back(fast_items[k]);
+        } else {
+            tree.wide.clear();
+        }
     }
 
     RTX_HIP(ctx->prims.upload(prims_padded));
@@ -703,6 +714,8 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     RTX_HIP(ctx->scan_info.upload(scan_info));
     RTX_HIP(ctx->scan_orig.upload(scan_orig));
     RTX_HIP(ctx->bvh.upload(nodes));
+    RTX_HIP(ctx->bvh_wide.upload(tree.wide));
+    RTX_HIP(ctx->wide_items.upload(wide_items));
     RTX_HIP(ctx->bvh_items.upload(items));
     RTX_HIP(ctx->bvh_fast.upload(fast_items));
     RTX_HIP(ctx->bvh_maps.upload(fast_maps));
@@ -726,6 +739,8 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     v.bvh_items = use_bvh ? ctx->bvh_items.ptr : nullptr;
     v.bvh_fast = use_bvh ? ctx->bvh_fast.ptr : nullptr;
     v.bvh_maps = use_bvh ? ctx->bvh_maps.ptr : nullptr;
+    v.bvh_wide = use_bvh && !tree.wide.empty() ? ctx->bvh_wide.ptr : nullptr;
+    v.wide_items = use_bvh ? ctx->wide_items.ptr : nullptr;
     std::memcpy(v.bvh_origin, tree.origin, sizeof v.bvh_origin);
     std::memcpy(v.bvh_scale, tree.scale, sizeof v.bvh_scale);
     v.n_bvh_big = tree.n_big;

@@ -31,6 +31,12 @@ struct Tree {
     std::vector<rtxd::Group> items;
     uint32_t n_big = 0;
     int depth = 0;  // inner-node levels above the deepest leaf
+    // the same tree collapsed into eight-wide nodes (rtxd::WideNode): wide[0] is the root,
+    // wide_order[k] = position in `items` of the wide tree's k-th leaf record, wide_depth =
+    // levels of wide nodes (what the wide traversal's stack has to hold)
+    std::vector<rtxd::WideNode> wide;
+    std::vector<uint32_t> wide_order;
+    int wide_depth = 0;
     float origin[3] = {0, 0, 0};
     float scale[3] = {1, 1, 1};
 };

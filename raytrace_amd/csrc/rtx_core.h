@@ -1593,6 +1593,76 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
 }
 
 #if !RTX_DET
+// ---------------------------------------------------------------------------
+// eight-wide tree (rtxd::WideNode): one node against one ray
+// ---------------------------------------------------------------------------
+// Byte k of a word as a float (v_cvt_f32_ubyte0..3).
+template <int K>
+RTX_DEV float ubyte(uint32_t w) { return (float)((w >> (8 * K)) & 0xffu); }
+
+// Child K of four (the near / far plane bytes of the three axes, four children per word).  A
+// child's box on the node's grid is p + q * 2^e; along the ray that is
+// t(q) = q * (2^e * inv) + (p * inv + noi), one conversion and one fma per plane.  Which of the
+// two planes of an axis the ray meets first depends only on the sign of its direction, so the
+// caller hands over the near and far bytes already selected: no min / max per axis.
+template <int K>
+RTX_DEV uint32_t wide_child(uint32_t xn, uint32_t yn, uint32_t zn, uint32_t xf, uint32_t yf, uint32_t zf, V3 s, V3 b,
+                            float t0, float closest, uint32_t meta4, uint32_t index4, uint32_t hitmask) {
+    const float tnx = __builtin_fmaf(ubyte<K>(xn), s.x, b.x), tny = __builtin_fmaf(ubyte<K>(yn), s.y, b.y),
+                tnz = __builtin_fmaf(ubyte<K>(zn), s.z, b.z);
+    const float tfx = __builtin_fmaf(ubyte<K>(xf), s.x, b.x), tfy = __builtin_fmaf(ubyte<K>(yf), s.y, b.y),
+                tfz = __builtin_fmaf(ubyte<K>(zf), s.z, b.z);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz), t0);
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(tfx, tfy), tfz), closest);
+    // the slot's bits (1 for an inner node, its items in unary for a leaf, 0 for an empty slot)
+    // at the slot's place in the hit mask
+    const uint32_t bits = (meta4 >> (8 * K + 5)) & 7u, index = (index4 >> (8 * K)) & 31u;
+    return tn <= tf ? hitmask | (bits << index) : hitmask;
+}
+
+// The hit mask of one node: bits 24-31 the inner children the ray meets, placed in the order
+// the ray wants to visit them (highest bit first), bits 0-23 the items of the leaves it meets
+// (relative to the node's item_base).
+RTX_DEV uint32_t wide_node_hits(uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint4 n4, V3 inv, V3 noi, uint32_t oct_inv4,
+                                float t0, float closest) {
+    V3 s, b;
+    s.x = __uint_as_float((n0.w & 0xffu) << 23) * inv.x;
+    s.y = __uint_as_float((n0.w & 0xff00u) << 15) * inv.y;
+    s.z = __uint_as_float((n0.w & 0xff0000u) << 7) * inv.z;
+    b.x = __builtin_fmaf(__uint_as_float(n0.x), inv.x, noi.x);
+    b.y = __builtin_fmaf(__uint_as_float(n0.y), inv.y, noi.y);
+    b.z = __builtin_fmaf(__uint_as_float(n0.z), inv.z, noi.z);
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    // words: n2 = qlo.x[0-3] qlo.x[4-7] qlo.y[0-3] qlo.y[4-7]; n3 = qlo.z.. qlo.z.. qhi.x.. qhi.x..;
+    //        n4 = qhi.y.. qhi.y.. qhi.z.. qhi.z..
+    uint32_t hitmask = 0u;
+    {
+        const uint32_t xn = nx ? n3.z : n2.x, xf = nx ? n2.x : n3.z;
+        const uint32_t yn = ny ? n4.x : n2.z, yf = ny ? n2.z : n4.x;
+        const uint32_t zn = nz ? n4.z : n3.x, zf = nz ? n3.x : n4.z;
+        const uint32_t meta4 = n1.z;
+        const uint32_t inner4 = ((meta4 & (meta4 << 1)) & 0x10101010u) << 3;  // 0x80 in the bytes of inner slots
+        const uint32_t index4 = meta4 ^ (oct_inv4 & ((inner4 - (inner4 >> 7)) | inner4));
+        hitmask = wide_child<0>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
+        hitmask = wide_child<1>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
+        hitmask = wide_child<2>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
+        hitmask = wide_child<3>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
+    }
+    {
+        const uint32_t xn = nx ? n3.w : n2.y, xf = nx ? n2.y : n3.w;
+        const uint32_t yn = ny ? n4.y : n2.w, yf = ny ? n2.w : n4.y;
+        const uint32_t zn = nz ? n4.w : n3.y, zf = nz ? n3.y : n4.w;
+        const uint32_t meta4 = n1.w;
+        const uint32_t inner4 = ((meta4 & (meta4 << 1)) & 0x10101010u) << 3;
+        const uint32_t index4 = meta4 ^ (oct_inv4 & ((inner4 - (inner4 >> 7)) | inner4));
+        hitmask = wide_child<0>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
+        hitmask = wide_child<1>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
+        hitmask = wide_child<2>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
+        hitmask = wide_child<3>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
+    }
+    return hitmask;
+}
+
 // BVH scenes, fast mode: the same pool of (pixel, sample) items per wave, but traversal and
 // shading are decoupled.  A lane is idle, traversing, or holds a finished nearest-hit query;
 // each iteration of the wave performs ONE traversal step (a node, or a leaf) for the lanes
@@ -1607,7 +1677,7 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
                             // scene (5.52 Grays/s), 32 on the 487-sphere field; 24: 5.45 / 20.9
 #endif
 #ifndef RTX_WALK_STEPS
-#define RTX_WALK_STEPS 16   // traversal steps between two looks at the wave's state (1 .. 32 measured)
+#define RTX_WALK_STEPS 4    // traversal steps between two looks at the wave's state (1 .. 16 measured)
 #endif
 constexpr uint32_t kShadeBatch = RTX_SHADE_BATCH;
 #ifndef RTX_LEAF_BATCH
@@ -1624,10 +1694,22 @@ constexpr uint32_t kLeafBatch = RTX_LEAF_BATCH;
 #define RTX_BVH_WAVES 6  // minimum resident waves per SIMD the kernel is compiled for (80 VGPRs, none spilled; 5: 82)
 #endif
 
+// Development aid (-DRTX_BVH_STATS, tools/bvh_stats.py): per-wave event counts, added up in the
+// eight 64-bit words behind the ray counter.
+#ifdef RTX_BVH_STATS
+#define RTX_STAT(i, n) (stat[i] += (n))
+#else
+#define RTX_STAT(i, n) ((void)0)
+#endif
+
 template <bool kLightTree, bool kSamples>
 __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel(const TraceArgs a) {
+#ifdef RTX_BVH_STATS
+    uint32_t stat[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // wave-uniform
+#endif
     __shared__ float s_acc[RTX_BVH_BLOCK / 64][3][64];
-    __shared__ uint32_t s_stack[kBvhStack][RTX_BVH_BLOCK];
+    // per lane: the node groups of the levels above that still have children to visit
+    __shared__ uint2 s_stack[kWideStackEntries][RTX_BVH_BLOCK];
     const SceneView& sc = a.scene;
     const uint32_t tid = threadIdx.x, lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1654,14 +1736,27 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
     ps.depth = 0;
     ps.rng.state = 0;
     ps.rng.inc = 1;
-    // the query in flight
-    constexpr uint32_t kDone = 0xffffffffu;
-    uint32_t ref = kDone, sp = 0, best = kNone;
+    // The query in flight.  A node group is the children of one node that the ray still has to
+    // visit: the index of the node's first inner child and (hit bits << 24 | the node's imask);
+    // an item group the leaf records still to test: the node's item_base and their bits.
+    uint32_t ng_base = 0u, ng_bits = 0u, ig_base = 0u, ig_bits = 0u, oct_inv4 = 0u;
+    uint32_t sp = 0, best = kNone;
     float closest = kFltMax;
     V3 inv = v3(0.0f, 0.0f, 0.0f), noi = inv;
-    BvhRay br;
-    br.A = br.B = inv;
     const float fnx = (float)a.width, fny = (float)a.height;
+// the next group of this lane: from its stack, or the query is done (a macro: a lambda capturing
+// the traversal state by reference put part of it into scratch memory)
+#define RTX_NEXT_GROUP()                             \
+    do {                                             \
+        if (sp == 0u) {                              \
+            phase = kDoneWalk;                       \
+        } else {                                     \
+            --sp;                                    \
+            const uint2 e_ = s_stack[sp][tid];       \
+            ng_base = e_.x;                          \
+            ng_bits = e_.y;                          \
+        }                                            \
+    } while (0)
 
     for (;;) {
         const unsigned long long walking = __ballot(phase == kWalk);
@@ -1670,6 +1765,8 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
         const bool pool_left = next < total;
         const uint32_t waiting = n_done + (pool_left ? (uint32_t)__popcll(idle) : 0u);
         if (waiting != 0u && (walking == 0ull || waiting >= kShadeBatch)) {
+            RTX_STAT(5, 1u);      // [5] shade / refill passes of the wave
+            RTX_STAT(6, n_done);  // [6] ... lanes shaded
             if (phase == kDoneWalk) {  // Scene::color for the finished query
                 ++segs;
                 V3 L;
@@ -1731,8 +1828,14 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 inv = v3(__builtin_amdgcn_fmed3f(frcp(ps.d.x), -kBig, kBig), __builtin_amdgcn_fmed3f(frcp(ps.d.y), -kBig, kBig),
                          __builtin_amdgcn_fmed3f(frcp(ps.d.z), -kBig, kBig));
                 noi = v3(-ps.o.x * inv.x, -ps.o.y * inv.y, -ps.o.z * inv.z);
-                br = bvh_ray(sc, inv, noi);
-                ref = 0u;  // root
+                {   // slots are visited in ascending order of slot ^ octant: 7 - octant in every byte
+                    const uint32_t oct = (__float_as_uint(inv.x) >> 31) | ((__float_as_uint(inv.y) >> 31) << 1) |
+                                         ((__float_as_uint(inv.z) >> 31) << 2);
+                    oct_inv4 = (7u - oct) * 0x01010101u;
+                }
+                ng_base = 0u;  // the root as the one child of a group without inner-node mask: node 0
+                ng_bits = 0x80000000u;
+                ig_bits = 0u;
                 sp = 0u;
                 closest = kFltMax;
                 best = kNone;
@@ -1749,38 +1852,50 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
         }
 #pragma unroll 1
         for (int step = 0; step < RTX_WALK_STEPS; ++step) {
-            // lanes at an inner node take one step down; lanes that reached a leaf hold it until
-            // kLeafBatch of them have one (or nobody is left at a node), so that the leaf code
-            // - four record types, each its own branch - runs on a fuller wave
-            const bool at_leaf = phase == kWalk && (ref & kBvhLeaf) != 0u;
-            const bool at_node = phase == kWalk && !at_leaf;
+            RTX_STAT(4, 1u);  // [4] walk steps of the wave
+            // A lane with items left tests one; a lane without takes the next inner child of its
+            // node group one node down.  Lanes with items hold them until kLeafBatch of them have
+            // some (or nobody is left at a node), so that the leaf code - four record types, each
+            // its own branch - runs on a fuller wave.
+            const bool at_leaf = phase == kWalk && ig_bits != 0u;
+            const bool at_node = phase == kWalk && ig_bits == 0u;
             const unsigned long long nodes = __ballot(at_node);
             const uint32_t n_leaves = (uint32_t)__popcll(__ballot(at_leaf));
             if (nodes == 0ull && n_leaves == 0u) break;
+            RTX_STAT(7, (uint32_t)__popcll(__ballot(phase == kDoneWalk)));  // [7] lanes waiting to be shaded
+            RTX_STAT(8, (uint32_t)__popcll(__ballot(phase == kIdle)));      // [8] lanes without an item
+            RTX_STAT(9, n_leaves);                                           // [9] lanes holding leaf items
+            if (nodes != 0ull) {
+                RTX_STAT(0, 1u);                            // [0] node steps of the wave
+                RTX_STAT(1, (uint32_t)__popcll(nodes));     // [1] ... of its lanes
+            }
             if (at_node) {
-                const NodeWords N = load_node(sc, ref);
-                float n0, n1;
-                const bool h0 = slab(N.a.x, N.a.y, N.a.z, br, kTMin, closest, n0);
-                const bool h1 = slab(N.a.w, N.b.x, N.b.y, br, kTMin, closest, n1);
-                if (h0 & h1) {
-                    const bool first0 = n0 <= n1;
-                    if (sp < (uint32_t)kBvhStack) s_stack[sp][tid] = first0 ? N.b.w : N.b.z;
+                // the pending child the ray wants first: the highest hit bit
+                const uint32_t bit = 31u - (uint32_t)__clz((int)ng_bits);
+                ng_bits ^= 1u << bit;
+                const uint32_t slot = (bit - 24u) ^ (oct_inv4 & 7u);
+                const uint32_t node = ng_base + (uint32_t)__popc(ng_bits & ((1u << slot) - 1u));  // inner slots below it
+                if (ng_bits & 0xff000000u) {  // siblings left: they wait on the stack
+                    s_stack[sp][tid] = make_uint2(ng_base, ng_bits);
                     ++sp;
-                    ref = first0 ? N.b.z : N.b.w;
-                } else if (h0 | h1) {
-                    ref = h0 ? N.b.z : N.b.w;
-                } else {
-                    ref = pop_ref(s_stack, sp, tid);
                 }
-                if (ref == kDone) phase = kDoneWalk;
+                const uint4* p = reinterpret_cast<const uint4*>(sc.bvh_wide + node);
+                const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
+                const uint32_t hitmask = wide_node_hits(n0, n1, n2, n3, n4, inv, noi, oct_inv4, kTMin, closest);
+                ng_base = n1.x;
+                ng_bits = (hitmask & 0xff000000u) | (n0.w >> 24);
+                ig_base = n1.y;
+                ig_bits = hitmask & 0x00ffffffu;
+                if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
             }
             if (n_leaves >= kLeafBatch || (nodes == 0ull && n_leaves != 0u)) {
+                RTX_STAT(2, 1u);        // [2] item steps of the wave
+                RTX_STAT(3, n_leaves);  // [3] ... of its lanes
                 if (at_leaf) {
-                    const uint32_t first = ref & kBvhLeafFirst, count = (ref >> kBvhLeafCountShift) & 15u;
-                    for (uint32_t k = 0; k < count; ++k)
-                        fast_leaf_item(sc, sc.bvh_fast[first + k], ps.o, ps.d, inv, noi, kTMin, closest, best);
-                    ref = pop_ref(s_stack, sp, tid);
-                    if (ref == kDone) phase = kDoneWalk;
+                    const uint32_t k = (uint32_t)__ffs((int)ig_bits) - 1u;
+                    ig_bits &= ig_bits - 1u;
+                    fast_leaf_item(sc, sc.wide_items[ig_base + k], ps.o, ps.d, inv, noi, kTMin, closest, best);
+                    if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
                 }
             }
         }
@@ -1806,8 +1921,14 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
         uint32_t r = rays;
         for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
         if (lane == 0u) atomicAdd(a.rays, (unsigned long long)r);
+#ifdef RTX_BVH_STATS
+        if (lane == 0u)
+            for (int k = 0; k < 12; ++k) atomicAdd(a.rays + 1 + k, (unsigned long long)stat[k]);
+#endif
     }
 }
+#undef RTX_NEXT_GROUP
+#undef RTX_STAT
 #endif
 
 // Shape::hit of the world for arbitrary rays.

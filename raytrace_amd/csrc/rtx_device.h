@@ -159,6 +159,33 @@ constexpr uint32_t kBvhLeaf = 0x80000000u;
 constexpr uint32_t kBvhLeafFirst = 0x07ffffffu;
 constexpr uint32_t kBvhLeafCountShift = 27u;
 
+// Eight-wide tree for the fast-mode trace kernel (the two-child tree collapsed three levels at a
+// time).  Traversal of incoherent rays is bound by the chain of dependent node fetches, so a
+// node decides eight subtrees per fetch: 80 bytes = five 16-byte loads.  The children's boxes are
+// 8-bit coordinates on the node's own grid p + q * 2^e (per axis; rounded outwards), decoded
+// inside the slab test's fused multiply-adds.  Children that are inner nodes lie consecutively
+// from `child_base` in slot order; children that are leaves own consecutive records of
+// `wide_items` from `item_base`.  Per slot, `meta` is 0 (empty), 0x20 | (24 + slot) for an inner
+// node, or (count in unary: 1, 3, 7) << 5 | offset of its first item from item_base.  Slots are
+// assigned so that slot bit a set means "towards +axis a" within the node: a ray visits the
+// slots in ascending order of slot ^ octant(ray), which is roughly front to back and needs no
+// sorting.  (Layout after Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal on GPUs
+// Through Compressed Wide BVHs", 2017.)
+struct alignas(16) WideNode {
+    float p[3];
+    uint8_t e[3];       // biased fp32 exponent of the grid step per axis
+    uint8_t imask;      // bit s: slot s holds an inner node
+    uint32_t child_base;
+    uint32_t item_base;
+    uint8_t meta[8];
+    uint8_t qlo[3][8];  // [axis][slot]
+    uint8_t qhi[3][8];
+};
+static_assert(sizeof(WideNode) == 80, "five 16-byte loads");
+// Entries of the wide traversal's per-lane stack (8 bytes each): one per level that still has
+// unvisited children.  Deeper trees are rendered through the two-child tree instead.
+constexpr int kWideStackEntries = 12;
+
 // Fast-mode leaf record, one per BVH item in leaf order, so that a leaf costs one 32-byte
 // fetch instead of the chain item -> steps -> primitive:
 //   kBvhItemSphere  f = centre xyz, r*r                       (untransformed sphere)
@@ -202,6 +229,8 @@ struct SceneView {
                                // then the n_bvh_big groups outside the tree that every ray tests
     const BvhFastItem* bvh_fast;  // the same items as fast-mode leaf records
     const BvhMap* bvh_maps;       // affine maps of the box / group records
+    const WideNode* bvh_wide;        // eight-wide tree (null: not built or too deep for its stack)
+    const BvhFastItem* wide_items;   // leaf records in the wide tree's item order
     float bvh_origin[3], bvh_scale[3];  // the grid of the nodes' 16-bit boxes
     uint32_t bvh_big_first, n_bvh_big;
     uint32_t n_prims, n_groups, n_steps, n_materials, n_textures, n_lights, n_bvh_nodes;
