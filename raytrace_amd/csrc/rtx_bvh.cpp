@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "rtx.h"
 
@@ -147,23 +148,44 @@ void store_box(uint16_t lo[3], uint16_t hi[3], const Box& b, const Grid& g) {
 // fewer steps per ray).  Breadth-first emission, so that the inner children of a node are
 // consecutive.
 struct WideCost {
+    uint32_t first, n_items;  // the items below n: [first, first + n_items) in leaf order
+    bool as_leaf;             // cost(n, 1) is reached by turning n's whole subtree into one leaf
     double c[8];     // c[i], i = 1..7: cost(n, i)
     uint8_t k[9];    // k[j], j = 2..8: roots given to the left child when j are distributed over the two children
     uint8_t use[8];  // use[i], i = 2..7: the forest of cost(n, i) distributes this many (<= i; c(n, i - 1) may be as cheap)
 };
 
+// Cost of one leaf item relative to one visit of a wide node, and the most items a leaf of the wide
+// tree may hold (its meta byte counts them in unary, three bits).  RTX_WIDE_* in the environment
+// override them (experiments).
+double wide_leaf_cost() {
+    const char* e = std::getenv("RTX_WIDE_LEAF_COST");
+    return e ? std::atof(e) : 0.3;
+}
+uint32_t wide_leaf_items() {
+    const char* e = std::getenv("RTX_WIDE_LEAF_ITEMS");
+    const int v = e ? std::atoi(e) : 1;
+    return (uint32_t)std::min(std::max(v, 1), 3);
+}
+
 void wide_costs(const std::vector<TmpNode>& nodes, std::vector<WideCost>& cost) {
-    constexpr double kLeafCost = 0.3;
+    const double kLeafCost = wide_leaf_cost();
+    const uint32_t kMaxLeaf = wide_leaf_items();
     cost.assign(nodes.size(), WideCost{});
     // children lie behind their parent in `nodes`: a backward pass is a post-order pass
     for (size_t n = nodes.size(); n-- > 0;) {
         WideCost& C = cost[n];
         const double area = nodes[n].box.area();
         if (nodes[n].count != 0) {
-            for (int i = 1; i <= 7; ++i) C.c[i] = area * kLeafCost;
+            C.first = nodes[n].left;
+            C.n_items = nodes[n].count;
+            C.as_leaf = true;
+            for (int i = 1; i <= 7; ++i) C.c[i] = area * kLeafCost * C.n_items;
             continue;
         }
         const WideCost &L = cost[nodes[n].left], &R = cost[nodes[n].left + 1];
+        C.first = L.first;  // the left child's items come first and the right child's follow them
+        C.n_items = L.n_items + R.n_items;
         double dist[9];
         for (int j = 2; j <= 8; ++j) {
             dist[j] = DBL_MAX;
@@ -176,6 +198,10 @@ void wide_costs(const std::vector<TmpNode>& nodes, std::vector<WideCost>& cost) 
             }
         }
         C.c[1] = dist[8] + area;
+        if (C.n_items <= kMaxLeaf && area * kLeafCost * C.n_items < C.c[1]) {
+            C.c[1] = area * kLeafCost * C.n_items;
+            C.as_leaf = true;
+        }
         for (int i = 2; i <= 7; ++i) {
             if (dist[i] < C.c[i - 1]) {
                 C.c[i] = dist[i];
@@ -223,7 +249,7 @@ void build_wide(const std::vector<TmpNode>& nodes, Tree& out) {
         const Pending cur = queue[head];
         out.wide_depth = std::max(out.wide_depth, cur.depth);
         std::vector<uint32_t> kids;
-        if (nodes[cur.tmp].count != 0) {
+        if (cost[cur.tmp].as_leaf) {
             kids.push_back(cur.tmp);  // the whole tree is one leaf
         } else {  // the cheapest forest of at most eight roots below this node
             const int k = cost[cur.tmp].k[8];
@@ -279,21 +305,22 @@ void build_wide(const std::vector<TmpNode>& nodes, Tree& out) {
             }
             if (child_in[sidx] < 0) continue;
             const TmpNode& C = nodes[kids[child_in[sidx]]];
+            const WideCost& K = cost[kids[child_in[sidx]]];
             for (int a = 0; a < 3; ++a) {
                 const double l = std::floor((C.box.lo[a] - (double)W.p[a]) / step[a]);
                 const double h = std::ceil((C.box.hi[a] - (double)W.p[a]) / step[a]);
                 W.qlo[a][sidx] = (uint8_t)std::min(std::max(l, 0.0), 255.0);
                 W.qhi[a][sidx] = (uint8_t)std::min(std::max(h, 0.0), 255.0);
             }
-            if (C.count == 0) {
+            if (!K.as_leaf) {
                 W.imask |= (uint8_t)(1u << sidx);
                 W.meta[sidx] = (uint8_t)(0x20u | (24u + (uint32_t)sidx));
                 ++n_inner;
             } else {
                 const uint32_t offset = (uint32_t)out.wide_order.size() - W.item_base;  // < 24: at most 8 x 3 items
-                const uint32_t unary = (1u << C.count) - 1u;                           // count <= 3
+                const uint32_t unary = (1u << K.n_items) - 1u;                         // n_items <= 3
                 W.meta[sidx] = (uint8_t)((unary << 5) | offset);
-                for (uint32_t k = 0; k < C.count; ++k) out.wide_order.push_back(C.left + k);
+                for (uint32_t k = 0; k < K.n_items; ++k) out.wide_order.push_back(K.first + k);
             }
         }
         W.child_base = (uint32_t)out.wide.size();
