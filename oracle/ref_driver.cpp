@@ -308,4 +308,50 @@ int ref_light_pdf(void* p, int n, const float* org, const float* dir, uint64_t s
     }
     return 0;
 }
+
+/* Material::scatter / ::emitted / ::scattering_pdf (Material.h:9-11; Lambertian.cpp:16-25, Metal.cpp:9-17,
+ * Dielectric.cpp:7-45, DiffuseLight.h:17-28) of one material - kind 0 Lambertian, 1 Metal (param = fuzz),
+ * 2 Dielectric (param = refractive index), 3 DiffuseLight, over ColorTexture(tex) - for n (incoming
+ * direction, hit normal, scattered direction) triples at the hit point (0.5, 0.25, -1); entry k draws
+ * from the stream of (pixel k, sample 0, seed).  A material that does not scatter leaves dir at 0;
+ * Lambertian leaves it at 0 too (its direction is drawn by Scene::color from srec.pdf). */
+int ref_scatter(uint32_t kind, float param, const float* tex, int n, const float* d_in, const float* normals,
+                const float* scattered, uint64_t seed, int32_t* ok, int32_t* specular, float* dir, float* albedo,
+                float* emitted, float* spdf) {
+    TexturePtr t = std::make_shared<ColorTexture>(Vector3(tex[0], tex[1], tex[2]));
+    MaterialPtr m;
+    if (kind == 0) m = std::make_shared<Lambertian>(t);
+    else if (kind == 1) m = std::make_shared<Metal>(t, param);
+    else if (kind == 2) m = std::make_shared<Dielectric>(param);
+    else if (kind == 3) m = std::make_shared<DiffuseLight>(t);
+    else return -1;
+    for (int k = 0; k < n; ++k) {
+        HitRec h;
+        h.t = 1.0f;
+        h.u = h.v = 0.0f;
+        h.p = Vector3(0.5f, 0.25f, -1.0f);
+        h.n = Vector3(normals[3 * k], normals[3 * k + 1], normals[3 * k + 2]);
+        h.mat = m;
+        const Ray r(Vector3(0), Vector3(d_in[3 * k], d_in[3 * k + 1], d_in[3 * k + 2]));
+        ScatterRec srec;
+        srec.ray = Ray(Vector3(0), Vector3(0));
+        srec.albedo = Vector3(0);
+        srec.pdf = nullptr;
+        srec.is_specular = false;
+        rtx_rng_init(&g_rt_rng, uint32_t(k), 0u, seed);
+        const bool did = m->scatter(r, h, srec);
+        ok[k] = did ? 1 : 0;
+        specular[k] = srec.is_specular ? 1 : 0;
+        const Vector3 dd = srec.is_specular ? srec.ray.direction() : Vector3(0);
+        const Vector3 e = m->emitted(r, h);
+        const Ray sr(h.p, Vector3(scattered[3 * k], scattered[3 * k + 1], scattered[3 * k + 2]));
+        spdf[k] = m->scattering_pdf(sr, h);
+        for (int c = 0; c < 3; ++c) {
+            dir[3 * k + c] = dd[c];
+            albedo[3 * k + c] = kind == 3 ? tex[c] : srec.albedo[c];
+            emitted[3 * k + c] = e[c];
+        }
+    }
+    return 0;
+}
 }  // extern "C"

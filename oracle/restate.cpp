@@ -662,22 +662,26 @@ public:
         return cosine > F(0.0f) ? cosine / F(kPI) : F(0.0f);
     }
 
-    // Scene::color, Scene.cpp:103-132
-    Vec<F> color(const Vec<F>& o, const Vec<F>& d, int depth) {
-        Hit<F> rec;
-        if (!world_hit(o, d, F(0.001f), F(FLT_MAX), rec)) return background(d);
-        const uint32_t m = rec.material;
-        const uint32_t kind = sc.mat_kind[m];
-        // Material::emitted: Material.h:10, DiffuseLight.h:21-28
-        Vec<F> emitted(0.0f, 0.0f, 0.0f);
-        if (kind == RTX_MAT_DIFFUSE_LIGHT && dot(rec.n, d) < F(0.0f)) emitted = texture_value(sc.mat_texture[m], rec);
-        if (!(depth < m_max_depth)) return emitted;
+    // Material::scatter (Material.h:9) of the four materials: what ScatterRec (ScatterRec.h:7-12)
+    // carries out of it.  `albedo` is the value of the material's texture at the hit.
+    struct Scattered {
+        bool ok;        // scatter()'s return value
+        bool specular;  // ScatterRec::is_specular
+        Vec<F> dir;     // ScatterRec::ray's direction (specular materials; its origin is the hit point)
+        Vec<F> albedo;  // ScatterRec::albedo
+    };
+    Scattered scatter(uint32_t kind, F param, const Vec<F>& albedo, const Vec<F>& d, const Vec<F>& n) {
+        Scattered s;
+        s.ok = false;
+        s.specular = false;
+        s.dir = Vec<F>(0.0f, 0.0f, 0.0f);
+        s.albedo = albedo;
         switch (kind) {
             case RTX_MAT_DIFFUSE_LIGHT:  // DiffuseLight.h:17-19: scatter() is false
-                return emitted;
+                return s;
             case RTX_MAT_METAL: {  // Metal.cpp:9-17
                 Vec<F> nd = normalize(d);
-                Vec<F> reflected = nd - rec.n * (F(2.0f) * dot(nd, rec.n));  // reflect, Util.h:56-58
+                Vec<F> reflected = nd - n * (F(2.0f) * dot(nd, n));  // reflect, Util.h:56-58
                 Vec<F> q;
                 do {  // random_in_unit_sphere, Util.h:32-38; g++ evaluates the arguments of
                       // Vector3(drand48(), drand48(), drand48()) (Util.h:28-30) right to left
@@ -686,24 +690,25 @@ public:
                     F rx = draw();
                     q = Vec<F>(rx, ry, rz) * F(2.0f) - Vec<F>(1.0f, 1.0f, 1.0f);
                 } while (length_sqr(q) >= F(1.0f));
-                reflected = reflected + q * F(sc.mat_param[m]);
-                Vec<F> albedo = texture_value(sc.mat_texture[m], rec);
-                if (!(dot(reflected, rec.n) > F(0.0f))) return emitted;
-                return emitted + mul_per_elem(albedo, color(rec.p, reflected, depth + 1));  // Scene.cpp:110
+                reflected = reflected + q * param;
+                s.specular = true;
+                s.dir = reflected;
+                s.ok = dot(reflected, n) > F(0.0f);
+                return s;
             }
             case RTX_MAT_DIELECTRIC: {  // Dielectric.cpp:7-45
-                F ri = sc.mat_param[m];
-                Vec<F> reflected = d - rec.n * (F(2.0f) * dot(d, rec.n));
+                F ri = param;
+                Vec<F> reflected = d - n * (F(2.0f) * dot(d, n));
                 Vec<F> outward;
                 F ni_over_nt, cosine;
-                if (dot(d, rec.n) > F(0.0f)) {
-                    outward = -rec.n;
+                if (dot(d, n) > F(0.0f)) {
+                    outward = -n;
                     ni_over_nt = ri;
-                    cosine = ri * dot(d, rec.n) / length(d);
+                    cosine = ri * dot(d, n) / length(d);
                 } else {
-                    outward = rec.n;
+                    outward = n;
                     ni_over_nt = F(1.0f) / ri;
-                    cosine = -dot(d, rec.n) / length(d);
+                    cosine = -dot(d, n) / length(d);
                 }
                 // refract(-d, outward, ni_over_nt), Util.h:60-71
                 Vec<F> refracted;
@@ -721,35 +726,70 @@ public:
                         reflect_prob = r0 + (F(1.0f) - r0) * (mm * mm * mm * mm * mm);
                     }
                 }
-                Vec<F> dir = (draw() < reflect_prob) ? reflected : refracted;
-                // albedo (1,1,1): mulPerElem by one (Scene.cpp:110)
-                return emitted + mul_per_elem(Vec<F>(1.0f, 1.0f, 1.0f), color(rec.p, dir, depth + 1));
+                s.dir = (draw() < reflect_prob) ? reflected : refracted;
+                s.albedo = Vec<F>(1.0f, 1.0f, 1.0f);  // Dielectric.cpp:8
+                s.specular = true;
+                s.ok = true;
+                return s;
             }
-            default: {  // Lambertian.cpp:16-25 + Scene.cpp:112-125
-                Vec<F> albedo = texture_value(sc.mat_texture[m], rec);
-                Vec<F> dir;
-                F pdf_value;
-                if (sc.n_lights == 0) {
-                    // no light shape (not expressible in the reference, whose color() always mixes
-                    // with a ShapePdf): the material's own pdf, srec.pdf of Lambertian.cpp:19, alone
+            default:  // Lambertian.cpp:16-21: the direction is drawn by the caller from srec.pdf (CosinePdf)
+                s.ok = true;
+                return s;
+        }
+    }
+    // Lambertian::scattering_pdf, Lambertian.cpp:23-25
+    F scattering_pdf(const Vec<F>& n, const Vec<F>& dir) const {
+        F c2 = dot(n, normalize(dir));
+        return (c2 < F(0.0f) ? F(0.0f) : c2) / F(kPI);
+    }
+    // Material::emitted: Material.h:10, DiffuseLight.h:21-28 (`value` = the emission texture at the hit)
+    Vec<F> emitted_of(uint32_t kind, const Vec<F>& value, const Vec<F>& n, const Vec<F>& d) const {
+        if (kind == RTX_MAT_DIFFUSE_LIGHT && dot(n, d) < F(0.0f)) return value;
+        return Vec<F>(0.0f, 0.0f, 0.0f);
+    }
+
+    // Scene::color, Scene.cpp:103-132
+    Vec<F> color(const Vec<F>& o, const Vec<F>& d, int depth) {
+        Hit<F> rec;
+        if (!world_hit(o, d, F(0.001f), F(FLT_MAX), rec)) return background(d);
+        const uint32_t m = rec.material;
+        const uint32_t kind = sc.mat_kind[m];
+        Vec<F> emitted(0.0f, 0.0f, 0.0f);
+        if (kind == RTX_MAT_DIFFUSE_LIGHT && dot(rec.n, d) < F(0.0f)) emitted = texture_value(sc.mat_texture[m], rec);
+        if (!(depth < m_max_depth)) return emitted;
+        if (kind == RTX_MAT_DIFFUSE_LIGHT) return emitted;
+        const Vec<F> albedo = kind == RTX_MAT_DIELECTRIC ? Vec<F>(1.0f, 1.0f, 1.0f) : Vec<F>(0.0f, 0.0f, 0.0f);
+        // (the albedo texture of Metal.cpp:13 / Lambertian.cpp:17 is evaluated below, where its
+        // value is used: it draws no random numbers, so the order does not show)
+        Scattered s = scatter(kind, F(sc.mat_param[m]), albedo, d, rec.n);
+        if (s.specular) {
+            if (kind == RTX_MAT_METAL) s.albedo = texture_value(sc.mat_texture[m], rec);
+            if (!s.ok) return emitted;
+            return emitted + mul_per_elem(s.albedo, color(rec.p, s.dir, depth + 1));  // Scene.cpp:110
+        }
+        {   // Lambertian.cpp:16-25 + Scene.cpp:112-125
+            s.albedo = texture_value(sc.mat_texture[m], rec);
+            Vec<F> dir;
+            F pdf_value;
+            if (sc.n_lights == 0) {
+                // no light shape (not expressible in the reference, whose color() always mixes
+                // with a ShapePdf): the material's own pdf, srec.pdf of Lambertian.cpp:19, alone
+                dir = cosine_generate(rec.n);
+                pdf_value = cosine_value(rec.n, dir);
+            } else {
+                if (draw() < F(0.5f))  // MixturePdf::generate, MixturePdf.h:15-22
+                    dir = light_random(rec.p);
+                else
                     dir = cosine_generate(rec.n);
-                    pdf_value = cosine_value(rec.n, dir);
-                } else {
-                    if (draw() < F(0.5f))  // MixturePdf::generate, MixturePdf.h:15-22
-                        dir = light_random(rec.p);
-                    else
-                        dir = cosine_generate(rec.n);
-                    // MixturePdf::value, MixturePdf.h:9-13
-                    F pdf0 = light_pdf(rec.p, dir);
-                    F pdf1 = cosine_value(rec.n, dir);
-                    pdf_value = F(0.5f) * pdf0 + F(0.5f) * pdf1;
-                }
-                if (!(pdf_value > F(0.0f))) return emitted;
-                F c2 = dot(rec.n, normalize(dir));  // Lambertian::scattering_pdf, Lambertian.cpp:23-25
-                F spdf = (c2 < F(0.0f) ? F(0.0f) : c2) / F(kPI);
-                Vec<F> weight = albedo * spdf;
-                return emitted + mul_per_elem(weight, color(rec.p, dir, depth + 1)) / pdf_value;  // Scene.cpp:120
+                // MixturePdf::value, MixturePdf.h:9-13
+                F pdf0 = light_pdf(rec.p, dir);
+                F pdf1 = cosine_value(rec.n, dir);
+                pdf_value = F(0.5f) * pdf0 + F(0.5f) * pdf1;
             }
+            if (!(pdf_value > F(0.0f))) return emitted;
+            F spdf = scattering_pdf(rec.n, dir);
+            Vec<F> weight = s.albedo * spdf;
+            return emitted + mul_per_elem(weight, color(rec.p, dir, depth + 1)) / pdf_value;  // Scene.cpp:120
         }
     }
 
@@ -936,6 +976,33 @@ int restate_light_pdf(const RtxScene* scene, int n, const float* org, const floa
         rtx_rng_init(&tr.rng, uint32_t(k), 0u, seed);
         const Vec<float> d = tr.light_random(o);
         dirs[3 * k] = d.x; dirs[3 * k + 1] = d.y; dirs[3 * k + 2] = d.z;
+    }
+    return 0;
+}
+
+/* Material::scatter / ::emitted / ::scattering_pdf of one material (kind RTX_MAT_*, param = fuzz or
+ * refractive index, plain-colour texture `tex`) for n (incoming direction, hit normal, scattered
+ * direction) triples; entry k draws from the stream of (pixel k, sample 0, seed).  Same outputs as
+ * ref_scatter() of oracle/ref_driver.cpp. */
+int restate_scatter(uint32_t kind, float param, const float* tex, int n, const float* d_in, const float* normals,
+                    const float* scattered, uint64_t seed, int32_t* ok, int32_t* specular, float* dir, float* albedo,
+                    float* emitted, float* spdf) {
+    RtxScene empty{};
+    Tracer<float> tr(empty, 50, nullptr);
+    const Vec<float> value(tex[0], tex[1], tex[2]);
+    for (int k = 0; k < n; ++k) {
+        const Vec<float> d(d_in[3 * k], d_in[3 * k + 1], d_in[3 * k + 2]), nn(normals[3 * k], normals[3 * k + 1], normals[3 * k + 2]);
+        const Vec<float> sd(scattered[3 * k], scattered[3 * k + 1], scattered[3 * k + 2]);
+        rtx_rng_init(&tr.rng, uint32_t(k), 0u, seed);
+        auto s = tr.scatter(kind, param, value, d, nn);
+        ok[k] = s.ok ? 1 : 0;
+        specular[k] = s.specular ? 1 : 0;
+        const Vec<float> e = tr.emitted_of(kind, value, nn, d);
+        const float sp = kind == RTX_MAT_LAMBERTIAN ? tr.scattering_pdf(nn, sd) : 0.0f;  // Material.h:11: 0 by default
+        dir[3 * k] = s.dir.x; dir[3 * k + 1] = s.dir.y; dir[3 * k + 2] = s.dir.z;
+        albedo[3 * k] = s.albedo.x; albedo[3 * k + 1] = s.albedo.y; albedo[3 * k + 2] = s.albedo.z;
+        emitted[3 * k] = e.x; emitted[3 * k + 1] = e.y; emitted[3 * k + 2] = e.z;
+        spdf[k] = sp;
     }
     return 0;
 }

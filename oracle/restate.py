@@ -143,3 +143,23 @@ def cosine_pdf(normals, seed=0):
     lib.restate_cosine_pdf(C.c_int(nn.shape[0]), C.c_void_p(nn.ctypes.data), C.c_uint64(seed),
                             C.c_void_p(dirs.ctypes.data), C.c_void_p(vals.ctypes.data))
     return dirs, vals
+
+
+def scatter(kind, param, tex, d_in, normals, scattered, seed=0):
+    """Material::scatter / emitted / scattering_pdf of one material (kind: 0 Lambertian, 1 Metal,
+    2 Dielectric, 3 DiffuseLight; param = fuzz | refractive index; tex = its plain colour) for n
+    (incoming direction, hit normal, scattered direction) triples; entry k draws from the stream
+    of (pixel k, sample 0, seed).  Returns dict(ok, specular, dir, albedo, emitted, spdf)."""
+    lib = load()
+    d = np.ascontiguousarray(d_in, np.float32).reshape(-1, 3)
+    nn = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    sd = np.ascontiguousarray(scattered, np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(tex, np.float32).reshape(3)
+    n = d.shape[0]
+    out = {"ok": np.zeros(n, np.int32), "specular": np.zeros(n, np.int32), "dir": np.zeros((n, 3), np.float32),
+           "albedo": np.zeros((n, 3), np.float32), "emitted": np.zeros((n, 3), np.float32), "spdf": np.zeros(n, np.float32)}
+    rc = lib.restate_scatter(C.c_uint32(kind), C.c_float(param), C.c_void_p(t.ctypes.data), C.c_int(n), C.c_void_p(d.ctypes.data),
+                        C.c_void_p(nn.ctypes.data), C.c_void_p(sd.ctypes.data), C.c_uint64(seed),
+                        *[C.c_void_p(out[k].ctypes.data) for k in ("ok", "specular", "dir", "albedo", "emitted", "spdf")])
+    assert rc == 0
+    return out

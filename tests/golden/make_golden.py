@@ -5,7 +5,7 @@ oracle/Makefile, fed the counter-based stream of include/rtx_det.h).
 
 Run from the repository root in a container that holds /root/reference:
     make -C oracle && python tests/golden/make_golden.py [section ...]
-(sections: texture samples hits misc pieces lights flops gt resolve; default all but "resolve_exhaustive"; "samples:textured" and
+(sections: texture samples hits misc pieces lights scatter flops gt gt_ref resolve; default all but "resolve_exhaustive"; "samples:textured" and
 "hits:textured" restrict a section to one scene).
 The reference has no fixtures of its own for this path, so these files are what pins
 the CPU restatement (and through it the GPU path) wherever the reference is absent.
@@ -136,6 +136,12 @@ def main(argv):
         flops_per_ray()
     if want("gt"):
         ground_truth()
+    if want("scatter"):
+        scatter_vectors(np.random.default_rng(2031))
+    if want("gt_ref"):
+        for spec in GT_REF:
+            if want("gt_ref") or want("gt_ref", spec[0]):
+                ground_truth_ref(*spec)
     if want("resolve") or want("resolve_exhaustive"):
         resolve_thresholds(exhaustive=want("resolve_exhaustive"))
 
@@ -241,6 +247,92 @@ def ground_truth():
     np.savez_compressed(os.path.join(HERE, "ground_truth_cornell_160x90.npz"), mean=gt.astype(np.float32),
                         spp=np.int32(spp))
     print("ground truth done", gt.mean())
+
+
+SCATTER_MATERIALS = [  # name, kind, param, texture colour
+    ("lambertian", 0, 0.0, (0.4, 0.2, 0.1)),
+    ("metal_fuzz0", 1, 0.0, (0.8, 0.85, 0.88)),
+    ("metal_fuzz03", 1, 0.3, (0.7, 0.6, 0.5)),
+    ("dielectric15", 2, 1.5, (1.0, 1.0, 1.0)),
+    ("dielectric24", 2, 2.4, (1.0, 1.0, 1.0)),
+    ("diffuse_light", 3, 0.0, (15.0, 15.0, 15.0)),
+]
+
+
+def scatter_inputs(rng, n=1024):
+    """(incoming direction, unit normal, scattered direction) triples: unnormalised directions of
+    all lengths (Dielectric.cpp:19,24 divide by the length), both sides of the surface, grazing
+    incidence (total internal reflection, Metal's dot <= 0 rejection)."""
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[::5] *= np.float32(300.0)
+    d[1::7] *= np.float32(1e-3)
+    nn = rng.normal(size=(n, 3)).astype(np.float32)
+    nn /= np.linalg.norm(nn, axis=1, keepdims=True).astype(np.float32)
+    graze = np.cross(nn[2::9], rng.normal(size=nn[2::9].shape)).astype(np.float32)
+    d[2::9] = graze + np.float32(0.02) * nn[2::9] * rng.choice([-1.0, 1.0], size=(graze.shape[0], 1)).astype(np.float32)
+    nn[:3] = [[0, 1, 0], [0, 0, -1], [1, 0, 0]]
+    d[:3] = [[0, -1, 0], [0, 0, -2], [0, 1, 0]]  # head-on, head-on from behind, parallel to the surface
+    sd = rng.normal(size=(n, 3)).astype(np.float32)
+    return d, nn, sd
+
+
+def scatter_vectors(rng):
+    """Material::scatter / emitted / scattering_pdf of the four materials, function by function,
+    from the reference's own classes (Lambertian.cpp:16-25, Metal.cpp:9-17, Dielectric.cpp:7-45,
+    DiffuseLight.h:17-28)."""
+    d, nn, sd = scatter_inputs(rng)
+    out = {"d": d, "n": nn, "scattered": sd, "seed": np.uint64(2032)}
+    for name, kind, param, tex in SCATTER_MATERIALS:
+        r = ref.scatter(kind, param, tex, d, nn, sd, seed=2032)
+        for k, v in r.items():
+            out[f"{name}_{k}"] = v.astype(np.int8) if k in ("ok", "specular") else v
+        print("scatter", name, "scattered:", int(r["ok"].sum()), "of", d.shape[0], "specular:", int(r["specular"].sum()))
+    np.savez_compressed(os.path.join(HERE, "scatter.npz"), **out)
+
+
+# Ground truths from the reference tracer itself for the statistical tests of the fast mode:
+# scene, width, height, samples per pixel of the ground truth, chunk.
+GT_REF = [
+    ("cornell", 480, 270, 16384, 1024),
+    ("cornell_extra", 240, 135, 4096, 1024),
+    ("random_field", 240, 135, 4096, 512),
+]
+
+
+def ground_truth_ref(name, w, h, spp, chunk, threads=7):
+    """High-spp mean image of the REFERENCE tracer (oracle/_ref), stored as fp16, and beside it
+    what the fast mode is compared with: the reference's own mean squared error against that
+    image at 64 and 512 samples per pixel (independent streams, several seeds), its rays per
+    sample, and the histogram of its path lengths (segments 1 .. 51)."""
+    import time
+
+    rs = ref.RefScene(name, w, h)
+    t0 = time.time()
+    acc = np.zeros((h, w, 3), np.float64)
+    rays = 0
+    base = 1 << 20  # sample indices far from those of any test
+    for b in range(0, spp, chunk):
+        r = rs.render(base + b, min(chunk, spp - b), seed=4242, threads=threads)
+        acc += r["sum"]
+        rays += r["rays"]
+        print(f"gt_ref {name}: {b + chunk}/{spp} spp, {time.time() - t0:.0f} s", flush=True)
+    mean = (acc / spp).astype(np.float32)
+    gt = np.clip(mean, 0, 1)
+    out = {"mean": mean.astype(np.float16), "spp": np.int32(spp), "rays_per_sample": np.float64(rays / (w * h * spp))}
+    for n, seeds in ((64, 6), (512, 3)):
+        mses = []
+        for sd in range(seeds):
+            img = rs.render(0, n, seed=1000 + sd, threads=threads)["sum"] / n
+            mses.append(float(np.mean((np.clip(img, 0, 1) - gt) ** 2)))
+        out[f"ref_mse_{n}"] = np.array(mses)
+        print(f"gt_ref {name}: reference MSE at {n} spp {np.mean(mses):.3e} +- {np.std(mses):.1e}", flush=True)
+    # path lengths: per-sample segment counts of a smaller run
+    ws, hs, ns = min(w, 240), min(h, 135), 64
+    seg = ref.RefScene(name, ws, hs).render(0, ns, seed=77, threads=threads, per_sample=True)["segments"]
+    out["segments_hist"] = np.bincount(seg.ravel(), minlength=52)[:52].astype(np.int64)
+    out["segments_hist_frame"] = np.array([ws, hs, ns], np.int32)
+    np.savez_compressed(os.path.join(HERE, f"ground_truth_ref_{name}_{w}x{h}.npz"), **out)
+    print(f"gt_ref {name} done in {time.time() - t0:.0f} s, mean {mean.mean():.5f}", flush=True)
 
 
 def _codes(bits):

@@ -220,3 +220,29 @@ def test_resolve_threshold_table_is_the_references_byte_staircase():
     assert np.array_equal(staircase(x), api.image_write(x))  # the product's host chain
     if ref.available():
         assert np.array_equal(staircase(x), ref.image_write(x))
+
+
+def test_material_scatter_functions_match_the_reference():
+    """Material::scatter / emitted / scattering_pdf function by function (Lambertian.cpp:16-25,
+    Metal.cpp:9-17 incl. the g++ draw order of the fuzz vector, Dielectric.cpp:7-45, DiffuseLight.h:17-28):
+    the restatement's material functions - the ones its color() calls - return the bits of the
+    reference's classes on 1 024 (direction, normal) pairs per material, fed the same streams."""
+    from tests.golden.make_golden import SCATTER_MATERIALS
+
+    g = util.load_golden("scatter")
+    for name, kind, param, tex in SCATTER_MATERIALS:
+        got = restate.scatter(kind, param, tex, g["d"], g["n"], g["scattered"], seed=int(g["seed"]))
+        for k in ("ok", "specular"):
+            assert np.array_equal(got[k], g[f"{name}_{k}"].astype(np.int32)), (name, k)
+        for k in ("dir", "albedo", "emitted", "spdf"):
+            assert np.array_equal(got[k], g[f"{name}_{k}"], equal_nan=True), (name, k)
+        if ref.available():  # the fixture is what the reference returns today
+            live = ref.scatter(kind, param, tex, g["d"], g["n"], g["scattered"], seed=int(g["seed"]))
+            for k in ("dir", "albedo", "emitted", "spdf"):
+                assert np.array_equal(live[k], g[f"{name}_{k}"], equal_nan=True), (name, k)
+    # the vectors exercise what they are meant to: both outcomes of Metal's rejection, both branches
+    # of the dielectric (reflection and refraction), emission on the front face only
+    assert 0 < g["metal_fuzz03_ok"].sum() < g["metal_fuzz03_ok"].size
+    assert 0 < g["diffuse_light_emitted"].any(axis=1).sum() < g["d"].shape[0]
+    assert g["diffuse_light_ok"].sum() == 0 and g["lambertian_ok"].all() and g["dielectric15_ok"].all()
+    assert (g["lambertian_spdf"] > 0).any() and (g["lambertian_spdf"] == 0).any()
