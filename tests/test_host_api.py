@@ -226,3 +226,26 @@ def test_scene_without_light_and_with_sky_background():
     assert int(a["background_mode"][0]) == api.RTX_BACKGROUND_SKY
     assert int(api.HostScene("small", 32, 18).arrays()["background_mode"][0]) == api.RTX_BACKGROUND_CONSTANT
     assert a["prim_kind"].size == 4 + 6  # four spheres and the six rects of the box
+
+
+def test_rtx_render_tool_parses_its_arguments_and_fails_loudly_without_a_gpu(tmp_path):
+    """raytrace_amd/rtx_render (the counterpart of main.cpp:7-20): usage errors exit with 2; on a
+    machine without a GPU a render fails with an error message and exit code 1 - there is no CPU
+    path to fall back to (on the GPU box the same call renders, see tests/test_host_e2e_gpu.py)."""
+    import subprocess
+
+    from raytrace_amd import api
+
+    exe = os.path.join(ROOT, "raytrace_amd", "rtx_render")
+    if not os.path.exists(exe):
+        pytest.skip("raytrace_amd/rtx_render not built")
+    if api.device_count() != 0:
+        pytest.skip("starts child processes: only where this process cannot have initialised a GPU")
+    r = subprocess.run([exe, "--bogus"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "usage" in r.stderr
+    r = subprocess.run([exe, "--devices", "x"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2
+    out = str(tmp_path / "o.bmp")
+    r = subprocess.run([exe, "--scene", "cornell_builtin", "--width", "16", "--height", "9", "--spp", "1", "--out", out,
+                        "--devices", "0,0"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "render failed" in r.stderr and not os.path.exists(out)
