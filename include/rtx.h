@@ -59,8 +59,11 @@ enum { RTX_LIGHTS_REFERENCE = 0, RTX_LIGHTS_GENERAL = 1 };
 enum { RTX_STEP_TRANSLATE = 0, RTX_STEP_ROTATE = 1 };
 /* Material kinds (Lambertian.h, Metal.h, Dielectric.h, DiffuseLight.h). */
 enum { RTX_MAT_LAMBERTIAN = 0, RTX_MAT_METAL = 1, RTX_MAT_DIELECTRIC = 2, RTX_MAT_DIFFUSE_LIGHT = 3 };
-/* Texture kinds (ColorTexture.h, CheckerTexture.h, ImageTexture.h). */
-enum { RTX_TEX_COLOR = 0, RTX_TEX_CHECKER = 1, RTX_TEX_IMAGE = 2 };
+/* Texture kinds (ColorTexture.h, CheckerTexture.h, ImageTexture.h).  SKY has no class of its own in
+ * the reference: its value at a point p is Scene::backgroundSky(p - centre) (Scene.h:24-28), the
+ * gradient the reference defines for rays that hit nothing; on an emitting sphere around the
+ * scene it is the sky as a surface, which the reference's own Scene::color can render. */
+enum { RTX_TEX_COLOR = 0, RTX_TEX_CHECKER = 1, RTX_TEX_IMAGE = 2, RTX_TEX_SKY = 3 };
 /* What a ray that hits nothing returns (Scene::background / Scene::backgroundSky, Scene.h:20-28). */
 enum { RTX_BACKGROUND_CONSTANT = 0, RTX_BACKGROUND_SKY = 1 };
 /* Acceleration structure choice for rtx_upload_scene(). */
@@ -115,7 +118,7 @@ typedef struct RtxScene {
     /* textures */
     uint32_t n_textures;
     const uint32_t* tex_kind;      /* RTX_TEX_* */
-    const float* tex_r;            /* colour: rgb (ColorTexture.h:15)                     */
+    const float* tex_r;            /* colour: rgb (ColorTexture.h:15); sky: the centre xyz  */
     const float* tex_g;            /* checker: tex_r = frequency (CheckerTexture.h:18)    */
     const float* tex_b;
     const uint32_t* tex_odd;       /* checker: sub-texture when the sine product is < 0; image: width  */

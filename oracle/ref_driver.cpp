@@ -34,6 +34,20 @@
 #include "ImageTexture.h"
 #include <stb_image_write.h> /* declarations only; the implementation is compiled in Scene.cpp:3-6 */
 
+// A texture the reference does not have, written against its Texture interface (Texture.h:5):
+// value(u, v, p) = the reference's own Scene::backgroundSky(p - centre) (Scene.h:24-28).  On an
+// emitting sphere around the scene it lets the UNMODIFIED Scene::color render - and sample as a
+// light - the sky gradient it never calls itself (scene "sky_sphere_lit").
+class SkyTexture : public Texture {
+public:
+    SkyTexture(const Vector3& centre) : m_centre(centre), m_scene("unused.bmp", 1, 1, 1) {}
+    virtual Vector3 value(float u, float v, const Vector3& p) const override { return m_scene.backgroundSky(p - m_centre); }
+
+private:
+    Vector3 m_centre;
+    Scene m_scene;
+};
+
 // internal linkage: the renderer's host library includes the same file against its own classes
 namespace {
 #include "../raytrace_amd/host/scenes.inc"

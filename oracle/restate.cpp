@@ -481,6 +481,8 @@ public:
             const uint8_t* t = sc.texels + sc.tex_offset[tex] + 3 * i + 3 * w * j;
             return Vec<F>(F((float)(int(t[0]) / 255.0)), F((float)(int(t[1]) / 255.0)), F((float)(int(t[2]) / 255.0)));
         }
+        if (sc.tex_kind[tex] == RTX_TEX_SKY)  // Scene::backgroundSky (Scene.h:24-28) of p - centre
+            return background_sky(h.p - Vec<F>(sc.tex_r[tex], sc.tex_g[tex], sc.tex_b[tex]));
         const Vec<F>& p = h.p;
         F freq = sc.tex_r[tex];
         F sines = f_sin(freq * p.x) * f_sin(freq * p.y) * f_sin(freq * p.z);
@@ -636,6 +638,9 @@ public:
     // Scene::background (Scene.h:20-22) or Scene::backgroundSky (Scene.h:24-28; lerp, vec_aos.h:92-95)
     Vec<F> background(const Vec<F>& d) const {
         if (sc.background_mode != RTX_BACKGROUND_SKY) return Vec<F>(sc.background[0], sc.background[1], sc.background[2]);
+        return background_sky(d);
+    }
+    Vec<F> background_sky(const Vec<F>& d) const {  // Scene.h:24-28
         Vec<F> v = normalize(d);
         F t = F(0.5f) * (v.y + F(1.0f));
         Vec<F> a(1.0f, 1.0f, 1.0f), b(0.5f, 0.7f, 1.0f);

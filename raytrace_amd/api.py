@@ -20,7 +20,7 @@ RTX_ACCEL_AUTO, RTX_ACCEL_LINEAR, RTX_ACCEL_BVH = 0, 1, 2
 RTX_MODE_FAST, RTX_MODE_DETERMINISTIC = 0, 1
 RTX_PRIM_RECT_XY, RTX_PRIM_RECT_XZ, RTX_PRIM_RECT_YZ, RTX_PRIM_SPHERE = 0, 1, 2, 3
 RTX_MAT_LAMBERTIAN, RTX_MAT_METAL, RTX_MAT_DIELECTRIC, RTX_MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
-RTX_TEX_COLOR, RTX_TEX_CHECKER, RTX_TEX_IMAGE = 0, 1, 2
+RTX_TEX_COLOR, RTX_TEX_CHECKER, RTX_TEX_IMAGE, RTX_TEX_SKY = 0, 1, 2, 3
 RTX_BACKGROUND_CONSTANT, RTX_BACKGROUND_SKY = 0, 1
 RTX_LIGHT_RECT_XY, RTX_LIGHT_RECT_XZ, RTX_LIGHT_RECT_YZ, RTX_LIGHT_SPHERE, RTX_LIGHT_OTHER, RTX_LIGHT_LIST = range(6)
 RTX_LIGHTS_REFERENCE, RTX_LIGHTS_GENERAL = 0, 1

@@ -167,7 +167,7 @@ int check_scene(const RtxScene* s) {
             return fail(RTX_ERR_INVALID_ARGUMENT, "mat_texture out of range");
     }
     for (uint32_t t = 0; t < s->n_textures; ++t) {
-        if (s->tex_kind[t] > RTX_TEX_IMAGE) return fail(RTX_ERR_INVALID_ARGUMENT, "bad tex_kind");
+        if (s->tex_kind[t] > RTX_TEX_SKY) return fail(RTX_ERR_INVALID_ARGUMENT, "bad tex_kind");
         if (s->tex_kind[t] == RTX_TEX_IMAGE) {
             const uint64_t need = (uint64_t)s->tex_odd[t] * s->tex_even[t] * 3u;
             if (need == 0 || (uint64_t)s->tex_offset[t] + need > s->n_texel_bytes)

@@ -856,6 +856,12 @@ RTX_DEV V3 texture_value(const SceneView& sc, uint32_t tex, float u, float v, V3
         const Texture T = sc.textures[tex];
         if (T.kind == RTX_TEX_COLOR) return v3(T.r, T.g, T.b);
         if (T.kind == RTX_TEX_IMAGE) return image_value(sc, T, u, v);
+        if (T.kind == RTX_TEX_SKY) {  // Scene::backgroundSky (Scene.h:24-28) of p - centre
+            const V3 w = normalize(p - v3(T.r, T.g, T.b));
+            const float t = 0.5f * (w.y + 1.0f);
+            const V3 white = v3(1.0f, 1.0f, 1.0f);
+            return white + (v3(0.5f, 0.7f, 1.0f) - white) * t;  // lerp, vec_aos.h:92-95
+        }
         float sines = (fsin(T.r * p.x) * fsin(T.r * p.y)) * fsin(T.r * p.z);
         tex = sines < 0.0f ? T.odd : T.even;
     }
@@ -913,6 +919,17 @@ RTX_DEV V3 onb_local(const Onb& b, V3 a) {  // ONB.h:24-26
 // of its own sampler, in the reference's order.
 constexpr uint32_t kSampleCosine = 5u;  // beyond the RTX_LIGHT_* kinds
 
+// cos(theta_max) of the cone a sphere fills seen from a point: sqrt(1 - rr / dd) with rr =
+// min(r^2, dd) (Sphere.cpp:44-46, 55-56).  From inside the sphere rr == dd; the approximate
+// reciprocal of fast mode can then land a hair above 1: clamp, so that the root is 0 and not NaN.
+RTX_DEV float cone_cosine(float rr, float dd) {
+#if RTX_DET
+    return fsqrt(1.0f - rr * frcp(dd));
+#else
+    return fsqrt(__builtin_fmaxf(1.0f - rr * frcp(dd), 0.0f));
+#endif
+}
+
 RTX_DEV V3 sample_direction(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
     uint32_t kind = kSampleCosine;
     Light E;
@@ -945,7 +962,7 @@ RTX_DEV V3 sample_direction(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
         float dd = length_sqr(axis);
         float r2r = E.d * E.d;
         float rr = dd < r2r ? dd : r2r;  // std::min(pow2(radius), distance_squared)
-        float cos_theta_max = fsqrt(1.0f - rr * frcp(dd));
+        float cos_theta_max = cone_cosine(rr, dd);
         z = 1.0f - r2 * (1.0f - cos_theta_max);
         radial = fsqrt(1.0f - z * z);
     } else {
@@ -974,7 +991,7 @@ RTX_DEV float light_pdf_one(const Light& E, V3 o, V3 v) {
         float dd = length_sqr(v3(E.a, E.b, E.c) - o);
         float r2r = E.d * E.d;
         float rr = dd < r2r ? dd : r2r;
-        float cos_theta_max = fsqrt(1.0f - rr * frcp(dd));
+        float cos_theta_max = cone_cosine(rr, dd);
         float solid_angle = kPi2 * (1.0f - cos_theta_max);
         return frcp(solid_angle);
     }
@@ -1016,7 +1033,7 @@ RTX_DEV float light_pdf_one_fast(const Light& E, V3 o, V3 v, float len2, float i
         const float D = h * h - len2 * (dd - r2);
         const bool ok = (D > 0.0f) & (fsqrt(D) - h > kTMin * len2);
         const float rr = dd < r2 ? dd : r2;
-        const float cos_theta_max = fsqrt(1.0f - rr * frcp(dd));
+        const float cos_theta_max = cone_cosine(rr, dd);
         return ok ? frcp(kPi2 * (1.0f - cos_theta_max)) : 0.0f;
     }
     return 0.0f;
@@ -1062,7 +1079,7 @@ RTX_DEV float light_pdf_leaf(const Light& E, V3 o, V3 v, bool general) {
         float dd = length_sqr(v3(E.a, E.b, E.c) - o);
         float r2r = E.d * E.d;
         float rr = dd < r2r ? dd : r2r;
-        float cos_theta_max = fsqrt(1.0f - rr * frcp(dd));
+        float cos_theta_max = cone_cosine(rr, dd);
         float solid_angle = kPi2 * (1.0f - cos_theta_max);
         return frcp(solid_angle);
     }
@@ -1164,7 +1181,7 @@ RTX_DEV V3 sample_direction_tree(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
             const float r2 = rng_nextf(&rng);
             float r2r = E.d * E.d;
             float rr = dd < r2r ? dd : r2r;
-            float cos_theta_max = fsqrt(1.0f - rr * frcp(dd));
+            float cos_theta_max = cone_cosine(rr, dd);
             float z = 1.0f - r2 * (1.0f - cos_theta_max);
             float radial = fsqrt(1.0f - z * z);
             float sn, cs;

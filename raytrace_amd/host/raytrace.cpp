@@ -243,6 +243,10 @@ uint32_t ColorTexture::flatten(FlatScene& f) const {
     return f.new_texture(RTX_TEX_COLOR, m_color.getX(), m_color.getY(), m_color.getZ(), 0, 0);
 }
 
+uint32_t SkyTexture::flatten(FlatScene& f) const {
+    return f.new_texture(RTX_TEX_SKY, m_centre.getX(), m_centre.getY(), m_centre.getZ(), 0, 0);
+}
+
 uint32_t CheckerTexture::flatten(FlatScene& f) const {
     uint32_t odd = f.intern_texture(m_odd);
     uint32_t even = f.intern_texture(m_even);

@@ -178,6 +178,18 @@ private:
     Vector3 m_color;
 };
 
+// No counterpart among the reference's texture classes: value(u, v, p) = Scene::backgroundSky(p - centre)
+// (Scene.h:24-28).  On an emitting sphere around the scene it turns the sky gradient into a
+// surface that Scene::color can render and sample as a light.
+class SkyTexture : public Texture {
+public:
+    SkyTexture(const Vector3& centre) : m_centre(centre) {}
+    uint32_t flatten(FlatScene& f) const override;
+
+private:
+    Vector3 m_centre;
+};
+
 class CheckerTexture : public Texture {
 public:
     CheckerTexture(const TexturePtr& t0, const TexturePtr& t1, float freq) : m_odd(t0), m_even(t1), m_freq(freq) {}

@@ -34,6 +34,7 @@ SAMPLE_CASES = [  # scene, w, h, spp_begin, spp, seed
     ("bvh_stress_500", 24, 14, 0, 2, 7),
     ("textured", 48, 27, 0, 8, 7),
     ("sky_spheres", 48, 27, 0, 8, 7),  # no light shape + sky: from the CPU restatement (see RESTATEMENT_ONLY)
+    ("sky_sphere_lit", 48, 27, 0, 8, 7),  # the sky gradient as an emitting sphere around the scene: the REFERENCE renders it
     ("cornell_light_tree", 48, 27, 0, 8, 7),   # nested light lists, XY rect / wrapped shapes with the default density
     ("cornell_side_lights", 48, 27, 0, 8, 7),  # general light sampling: from the CPU restatement
     ("cornell_many_lights", 48, 27, 0, 8, 7),  # a flat list of 40 lights

@@ -49,6 +49,8 @@ def _compare_samples(got_rgb, got_seg, want_rgb, want_seg):
     ("bvh_stress_2000", 32, 18, 2, api.RTX_ACCEL_BVH),
     ("textured", 64, 36, 8, api.RTX_ACCEL_LINEAR),
     ("textured", 64, 36, 8, api.RTX_ACCEL_BVH),
+    ("sky_sphere_lit", 64, 36, 8, api.RTX_ACCEL_LINEAR),  # Scene::backgroundSky as an emitting sphere around the scene
+    ("sky_sphere_lit", 64, 36, 8, api.RTX_ACCEL_BVH),
     ("cornell_light_tree", 64, 36, 8, api.RTX_ACCEL_LINEAR),  # nested light lists, shapes with the default density
     ("cornell_light_tree", 64, 36, 8, api.RTX_ACCEL_BVH),
     ("cornell_many_lights", 64, 36, 8, api.RTX_ACCEL_LINEAR),  # 40 lights in a flat list: the plain density sum
@@ -411,7 +413,7 @@ def test_fast_mode_hits_agree_with_golden_up_to_rounding(gpu_ctx, name, accel):
     assert du.max() < 5e-3
 
 
-@pytest.mark.parametrize("name", ["textured", "sky_spheres", "cornell_light_tree", "cornell_side_lights",
+@pytest.mark.parametrize("name", ["textured", "sky_spheres", "sky_sphere_lit", "cornell_light_tree", "cornell_side_lights",
                                   "cornell_many_lights_10"])
 def test_fast_mode_converges_on_widened_scenes(gpu_ctx, name):
     """Image textures / sky background without a light shape / light trees / general light
