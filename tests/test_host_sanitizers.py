@@ -1,0 +1,29 @@
+"""Host code under AddressSanitizer + UndefinedBehaviorSanitizer (no GPU): the scene flattener and
+the host image pipeline (raytrace_amd/host/raytrace.cpp, scene_factory.cpp), driven by
+tests/flatten_check.cpp over every named scene.  The tree builders have their own sanitizer run
+in tests/test_bvh_builder.py.  Device code cannot be sanitized on this pool; these are the parts of
+the library that run on the host for every scene upload."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_flattener_and_image_pipeline_are_clean_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "flatten_check")
+    host = os.path.join(ROOT, "raytrace_amd", "host")
+    # the render entry points of the host library call rtx_*: link the real library (its HIP
+    # runtime is loaded but never initialised: nothing here renders)
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=undefined", "-I" + os.path.join(ROOT, "include"), "-I" + host,
+           os.path.join(ROOT, "tests", "flatten_check.cpp"), os.path.join(host, "raytrace.cpp"),
+           os.path.join(host, "scene_factory.cpp"), "-L" + os.path.join(ROOT, "raytrace_amd"), "-lrtx",
+           "-Wl,-rpath," + os.path.join(ROOT, "raytrace_amd"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=0:protect_shadow_gap=0",
+               UBSAN_OPTIONS="print_stacktrace=1",
+               RTX_TEXTURE=os.path.join(ROOT, "tests", "golden", "texture_64x32.bmp"))
+    r = subprocess.run([exe, str(tmp_path / "o.bmp")], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-3000:]
+    assert os.path.getsize(str(tmp_path / "o.bmp")) == 54 + 5 * 24  # 7 pixels * 3 bytes padded to 24 per row

@@ -239,6 +239,56 @@ def test_fast_mode_converges_to_cpu_ground_truth(gpu_ctx):
     assert abs(np.clip(mean_fast / 4096, 0, 1).mean() - gt.mean()) < 0.002
 
 
+@pytest.mark.parametrize("name,w,h,accels", [
+    ("cornell", 480, 270, (api.RTX_ACCEL_LINEAR,)),
+    ("cornell_extra", 240, 135, (api.RTX_ACCEL_LINEAR, api.RTX_ACCEL_BVH)),
+    ("random_field", 240, 135, (api.RTX_ACCEL_BVH,)),
+])
+def test_fast_mode_against_the_references_own_ground_truth(gpu_ctx, name, w, h, accels):
+    """The default (fast) mode against images of the REFERENCE tracer (oracle/_ref, fixtures made by
+    tests/golden/make_golden.py gt_ref): a 16 384-spp (Cornell box, 480x270) / 4 096-spp (240x135)
+    mean image, the reference's own mean squared error against it at 64 and 512 samples per pixel,
+    and the histogram of its path lengths.  The fast mode must (1) have the reference's error at
+    equal sample counts - an estimator of another variance, or a biased one, shows here -, (2) agree
+    in the image mean to 0.1 %, (3) follow paths of the same length distribution; the deterministic
+    mode must reproduce the reference's path lengths exactly (same stream)."""
+    g = util.load_golden(f"ground_truth_ref_{name}_{w}x{h}")
+    mean = g["mean"].astype(np.float32)
+    gt = np.clip(mean, 0, 1)
+    scene = api.HostScene(name, w, h)
+    for accel in accels:
+        gpu_ctx.upload(scene, accel)
+        for n, seeds in ((64, 16), (512, 6)):
+            want = g[f"ref_mse_{n}"]
+            got = np.array([float(np.mean((np.clip(gpu_ctx.render(gpu_ctx.params(w, h, 0, n, seed=500 + s))[0] / n, 0, 1) - gt) ** 2))
+                            for s in range(seeds)])
+            ratio = got.mean() / want.mean()
+            sigma = np.sqrt(got.var() / got.size + want.var() / want.size) / want.mean()
+            assert abs(ratio - 1) < max(0.03, 4 * sigma), (accel, n, ratio, sigma)
+        big = 16384
+        img, rays = gpu_ctx.render(gpu_ctx.params(w, h, 0, big, seed=9))
+        assert np.isfinite(img).all()
+        assert abs(float(img.mean()) / big / float(mean.mean()) - 1) < 1e-3, (accel, float(img.mean()) / big, float(mean.mean()))
+        assert abs(rays / (w * h * big) / float(g["rays_per_sample"]) - 1) < 2e-3
+        # path lengths
+        ws, hs, ns = [int(v) for v in g["segments_hist_frame"]]
+        gpu_ctx.upload(api.HostScene(name, ws, hs), accel)
+        ref_hist = g["segments_hist"].astype(np.float64)
+        _, seg = gpu_ctx.render_samples(gpu_ctx.params(ws, hs, 0, ns, mode=api.RTX_MODE_DETERMINISTIC, seed=77))
+        assert np.array_equal(np.bincount(seg.ravel(), minlength=52)[:52], g["segments_hist"])  # the reference's stream
+        _, seg = gpu_ctx.render_samples(gpu_ctx.params(ws, hs, 0, ns, mode=api.RTX_MODE_FAST, seed=78))
+        fast_hist = np.bincount(seg.ravel(), minlength=52)[:52].astype(np.float64)
+        assert fast_hist.sum() == ref_hist.sum()
+        # two-sample chi-square over the lengths with enough samples; the tail pooled
+        keep = (ref_hist + fast_hist) >= 50
+        a = np.append(ref_hist[keep], ref_hist[~keep].sum())
+        b = np.append(fast_hist[keep], fast_hist[~keep].sum())
+        ok = (a + b) > 0
+        chi2 = float((((a - b) ** 2)[ok] / (a + b)[ok]).sum())
+        dof = int(ok.sum()) - 1
+        assert chi2 < dof + 5 * np.sqrt(2 * dof), (accel, chi2, dof)
+
+
 def test_sample_ranges_and_accumulate_compose(gpu_ctx):
     w, h = 80, 45
     scene = api.HostScene("cornell_extra", w, h)
