@@ -765,6 +765,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     std::memcpy(v.cam_v, s->cam_v, sizeof v.cam_v);
     std::memcpy(v.background, s->background, sizeof v.background);
     v.background_mode = s->background_mode;
+    rtxbvh::scene_bounds(prims, groups, steps, v.bounds_lo, v.bounds_hi);
 
     ctx->info.n_prims = s->n_prims;
     ctx->info.n_items = (uint32_t)groups.size();

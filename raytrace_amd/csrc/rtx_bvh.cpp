@@ -528,6 +528,16 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
     return true;
 }
 
+void scene_bounds(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,
+                  const std::vector<rtxd::Step>& steps, float lo[3], float hi[3]) {
+    Box all;
+    for (const rtxd::Group& G : groups) all.add(group_box(prims, G, steps));
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = std::nextafterf((float)all.lo[a], -FLT_MAX);
+        hi[a] = std::nextafterf((float)all.hi[a], FLT_MAX);
+    }
+}
+
 namespace {
 struct LightItem {
     Box box;

@@ -45,6 +45,11 @@ struct Tree {
 bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,
            const std::vector<rtxd::Step>& steps, Tree& out, std::string& err);
 
+// Bounds of the whole scene (every group's padded world-space box, as the trees use them), rounded
+// outwards to fp32: a ray that does not meet them meets no primitive.
+void scene_bounds(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,
+                  const std::vector<rtxd::Step>& steps, float lo[3], float hi[3]);
+
 // Tree over the light leaves for the density sum (rtxd::LightBvhNode): group g of `groups` is
 // one light leaf (its shape as a primitive, its transform chain), `entries[g]` the index the
 // leaf's node carries.  Median splits on the widest axis of the centres, one leaf per node,

@@ -804,6 +804,23 @@ RTX_DEV bool query_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, floa
     return best != kNone;
 }
 
+#if !RTX_DET
+// Whether a ray can meet anything at all: the slab test against the bounds of the whole scene
+// (conservative: NaNs and rays parallel to a slab count as "can").
+RTX_DEV bool ray_meets_scene(const SceneView& sc, V3 o, V3 d, float t0) {
+    constexpr float kBig = 1.0e18f;
+    const V3 inv = v3(__builtin_amdgcn_fmed3f(frcp(d.x), -kBig, kBig), __builtin_amdgcn_fmed3f(frcp(d.y), -kBig, kBig),
+                      __builtin_amdgcn_fmed3f(frcp(d.z), -kBig, kBig));
+    const float lx = (sc.bounds_lo[0] - o.x) * inv.x, hx = (sc.bounds_hi[0] - o.x) * inv.x;
+    const float ly = (sc.bounds_lo[1] - o.y) * inv.y, hy = (sc.bounds_hi[1] - o.y) * inv.y;
+    const float lz = (sc.bounds_lo[2] - o.z) * inv.z, hz = (sc.bounds_hi[2] - o.z) * inv.z;
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx, hx), __builtin_fminf(ly, hy)),
+                                     __builtin_fmaxf(__builtin_fminf(lz, hz), t0));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx, hx), __builtin_fmaxf(ly, hy)), __builtin_fmaxf(lz, hz));
+    return !(tn > tf);
+}
+#endif
+
 // The nearest-hit query proper (winner and distance) and, apart from it, the completion of the
 // winner's record: callers that branch on the outcome complete the record inside the branch that
 // uses it, so that it is not live on the path of a miss.
@@ -1553,7 +1570,18 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
         if (kBvh ? active : true) {
             float t_hit;
             uint32_t prim_hit;
+#if RTX_DET
             const bool hit = scene_query<kBvh>(sc, ps.o, ps.d, kTMin, kFltMax, t_hit, prim_hit);
+#else
+            // A wave whose rays all pass the scene by - the pixels of a tile that look past it - answers
+            // its queries from the scene's bounds and skips the scan (the linear scan is wave-uniform:
+            // it only pays when no lane needs it; the tree rejects such a ray at its root anyway).
+            // Only camera rays come from outside the scene: the test runs when every ray of the wave is one.
+            bool hit = false;
+            bool scan = kBvh || __ballot(active && ps.depth != 0u) != 0ull;
+            if (!scan) scan = __ballot(active && ray_meets_scene(sc, ps.o, ps.d, kTMin)) != 0ull;
+            if (scan) hit = scene_query<kBvh>(sc, ps.o, ps.d, kTMin, kFltMax, t_hit, prim_hit);
+#endif
             ++segs;
             V3 L;
             bool ended;

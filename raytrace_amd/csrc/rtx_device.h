@@ -241,6 +241,7 @@ struct SceneView {
     float cam_origin[3], cam_ll[3], cam_u[3], cam_v[3];
     float background[3];
     uint32_t background_mode;  // RTX_BACKGROUND_*
+    float bounds_lo[3], bounds_hi[3];  // padded bounds of all primitives: a ray outside them hits nothing
     const LightBvhNode* light_bvh;  // null: light_pdf_tree visits every leaf
     uint32_t n_light_bvh;
     uint32_t light_bvh_pad_;
