@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -358,6 +359,16 @@ void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rt
 
 // Fast-mode leaf records of the BVH items (groups in leaf order) and the hit-completion table
 // in their slot order.
+// Scenes with fewer tree items than this are traced through the two-child tree in fast mode.  0: the
+// eight-wide tree always.  Measured at 1080p (wide against two-child, Grays/s): 200 items 45.7 / 45.6,
+// 500 items 37.4 / 35.5, 1 000 items 29.9 / 28.8, 2 000 items 25.0 / 23.3, 100 000 items 6.42 / 5.93; only
+// the 487-sphere field prefers the two-child tree (21.0 / 21.7), so no item count separates the two.
+// RTX_WIDE_MIN_ITEMS overrides, for measurements.
+size_t wide_min_items() {
+    const char* e = std::getenv("RTX_WIDE_MIN_ITEMS");  // read at every upload: tests switch it
+    return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0;
+}
+
 void build_bvh_fast_items(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::PrimInfo>& info,
                           const std::vector<rtxd::Group>& items, const std::vector<rtxd::Step>& steps,
                           std::vector<rtxd::BvhFastItem>& out, std::vector<rtxd::BvhMap>& maps,
@@ -690,8 +701,9 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
             return fail(RTX_ERR_TOO_LARGE, "BVH is deeper than the traversal stack");
         build_bvh_fast_items(prims, info, items, steps, fast_items, fast_maps, scan_info, scan_orig);
         // the eight-wide tree of the fast trace kernel reads the leaf records in its own order; a
-        // tree deeper than that kernel's stack is rendered through the two-child tree instead
-        if (tree.wide_depth <= rtxd::kWideStackEntries) {
+        // tree deeper than that kernel's stack, or a small one, is rendered through the two-child
+        // tree instead
+        if (tree.wide_depth <= rtxd::kWideStackEntries && items.size() >= wide_min_items()) {
             wide_items.reserve(tree.wide_order.size());
             for (uint32_t k : tree.wide_order) wide_items.push_back(fast_items[k]);
         } else {

@@ -1747,14 +1747,21 @@ constexpr uint32_t kLeafBatch = RTX_LEAF_BATCH;
 #define RTX_STAT(i, n) ((void)0)
 #endif
 
-template <bool kLightTree, bool kSamples>
+// kWide: the eight-wide tree (sc.bvh_wide / sc.wide_items), else the two-child tree (sc.bvh /
+// sc.bvh_fast).  The wide tree's chain of dependent fetches is a third as long, but a step down
+// it costs about three times the instructions: it wins on large trees, the two-child tree on
+// small ones whose nodes all stay in the caches (see launch_trace).
+template <bool kLightTree, bool kSamples, bool kWide>
 __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel(const TraceArgs a) {
 #ifdef RTX_BVH_STATS
     uint32_t stat[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // wave-uniform
 #endif
     __shared__ float s_acc[RTX_BVH_BLOCK / 64][3][64];
-    // per lane: the node groups of the levels above that still have children to visit
+    // per lane: the node groups of the levels above that still have children to visit (wide
+    // tree), or the deferred children (two-child tree; the same 6 KB per wave either way)
     __shared__ uint2 s_stack[kWideStackEntries][RTX_BVH_BLOCK];
+    static_assert(sizeof(uint2) * kWideStackEntries == sizeof(uint32_t) * kBvhStack, "one LDS block, two views");
+    uint32_t (*s_stack2)[RTX_BVH_BLOCK] = reinterpret_cast<uint32_t (*)[RTX_BVH_BLOCK]>(&s_stack[0][0]);
     const SceneView& sc = a.scene;
     const uint32_t tid = threadIdx.x, lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1788,6 +1795,11 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
     uint32_t sp = 0, best = kNone;
     float closest = kFltMax;
     V3 inv = v3(0.0f, 0.0f, 0.0f), noi = inv;
+    // two-child tree: the node or leaf the lane stands at, the ray on the tree's grid
+    constexpr uint32_t kDone = 0xffffffffu;
+    uint32_t ref = kDone;
+    BvhRay br;
+    br.A = br.B = inv;
     const float fnx = (float)a.width, fny = (float)a.height;
 // the next group of this lane: from its stack, or the query is done (a macro: a lambda capturing
 // the traversal state by reference put part of it into scratch memory)
@@ -1873,14 +1885,17 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 inv = v3(__builtin_amdgcn_fmed3f(frcp(ps.d.x), -kBig, kBig), __builtin_amdgcn_fmed3f(frcp(ps.d.y), -kBig, kBig),
                          __builtin_amdgcn_fmed3f(frcp(ps.d.z), -kBig, kBig));
                 noi = v3(-ps.o.x * inv.x, -ps.o.y * inv.y, -ps.o.z * inv.z);
-                {   // slots are visited in ascending order of slot ^ octant: 7 - octant in every byte
+                if constexpr (kWide) {  // slots are visited in ascending order of slot ^ octant: 7 - octant in every byte
                     const uint32_t oct = (__float_as_uint(inv.x) >> 31) | ((__float_as_uint(inv.y) >> 31) << 1) |
                                          ((__float_as_uint(inv.z) >> 31) << 2);
                     oct_inv4 = (7u - oct) * 0x01010101u;
+                    ng_base = 0u;  // the root as the one child of a group without inner-node mask: node 0
+                    ng_bits = 0x80000000u;
+                    ig_bits = 0u;
+                } else {
+                    br = bvh_ray(sc, inv, noi);
+                    ref = 0u;  // root
                 }
-                ng_base = 0u;  // the root as the one child of a group without inner-node mask: node 0
-                ng_bits = 0x80000000u;
-                ig_bits = 0u;
                 sp = 0u;
                 closest = kFltMax;
                 best = kNone;
@@ -1902,8 +1917,8 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
             // node group one node down.  Lanes with items hold them until kLeafBatch of them have
             // some (or nobody is left at a node), so that the leaf code - four record types, each
             // its own branch - runs on a fuller wave.
-            const bool at_leaf = phase == kWalk && ig_bits != 0u;
-            const bool at_node = phase == kWalk && ig_bits == 0u;
+            const bool at_leaf = phase == kWalk && (kWide ? ig_bits != 0u : (ref & kBvhLeaf) != 0u);
+            const bool at_node = phase == kWalk && !at_leaf;
             const unsigned long long nodes = __ballot(at_node);
             const uint32_t n_leaves = (uint32_t)__popcll(__ballot(at_leaf));
             if (nodes == 0ull && n_leaves == 0u) break;
@@ -1914,33 +1929,61 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 RTX_STAT(0, 1u);                            // [0] node steps of the wave
                 RTX_STAT(1, (uint32_t)__popcll(nodes));     // [1] ... of its lanes
             }
-            if (at_node) {
-                // the pending child the ray wants first: the highest hit bit
-                const uint32_t bit = 31u - (uint32_t)__clz((int)ng_bits);
-                ng_bits ^= 1u << bit;
-                const uint32_t slot = (bit - 24u) ^ (oct_inv4 & 7u);
-                const uint32_t node = ng_base + (uint32_t)__popc(ng_bits & ((1u << slot) - 1u));  // inner slots below it
-                if (ng_bits & 0xff000000u) {  // siblings left: they wait on the stack
-                    s_stack[sp][tid] = make_uint2(ng_base, ng_bits);
-                    ++sp;
-                }
-                const uint4* p = reinterpret_cast<const uint4*>(sc.bvh_wide + node);
-                const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
-                const uint32_t hitmask = wide_node_hits(n0, n1, n2, n3, n4, inv, noi, oct_inv4, kTMin, closest);
-                ng_base = n1.x;
-                ng_bits = (hitmask & 0xff000000u) | (n0.w >> 24);
-                ig_base = n1.y;
-                ig_bits = hitmask & 0x00ffffffu;
-                if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
-            }
-            if (n_leaves >= kLeafBatch || (nodes == 0ull && n_leaves != 0u)) {
+            const bool leaves_now = n_leaves >= kLeafBatch || (nodes == 0ull && n_leaves != 0u);
+            if (leaves_now) {
                 RTX_STAT(2, 1u);        // [2] item steps of the wave
                 RTX_STAT(3, n_leaves);  // [3] ... of its lanes
-                if (at_leaf) {
+            }
+            if constexpr (kWide) {
+                if (at_node) {
+                    // the pending child the ray wants first: the highest hit bit
+                    const uint32_t bit = 31u - (uint32_t)__clz((int)ng_bits);
+                    ng_bits ^= 1u << bit;
+                    const uint32_t slot = (bit - 24u) ^ (oct_inv4 & 7u);
+                    const uint32_t node = ng_base + (uint32_t)__popc(ng_bits & ((1u << slot) - 1u));  // inner slots below it
+                    if (ng_bits & 0xff000000u) {  // siblings left: they wait on the stack
+                        s_stack[sp][tid] = make_uint2(ng_base, ng_bits);
+                        ++sp;
+                    }
+                    const uint4* p = reinterpret_cast<const uint4*>(sc.bvh_wide + node);
+                    const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
+                    const uint32_t hitmask = wide_node_hits(n0, n1, n2, n3, n4, inv, noi, oct_inv4, kTMin, closest);
+                    ng_base = n1.x;
+                    ng_bits = (hitmask & 0xff000000u) | (n0.w >> 24);
+                    ig_base = n1.y;
+                    ig_bits = hitmask & 0x00ffffffu;
+                    if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
+                }
+                if (leaves_now && at_leaf) {
                     const uint32_t k = (uint32_t)__ffs((int)ig_bits) - 1u;
                     ig_bits &= ig_bits - 1u;
                     fast_leaf_item(sc, sc.wide_items[ig_base + k], ps.o, ps.d, inv, noi, kTMin, closest, best);
                     if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
+                }
+            } else {
+                if (at_node) {
+                    const NodeWords N = load_node(sc, ref);
+                    float n0, n1;
+                    const bool h0 = slab(N.a.x, N.a.y, N.a.z, br, kTMin, closest, n0);
+                    const bool h1 = slab(N.a.w, N.b.x, N.b.y, br, kTMin, closest, n1);
+                    if (h0 & h1) {  // the nearer child first, the other waits on the stack
+                        const bool first0 = n0 <= n1;
+                        if (sp < (uint32_t)kBvhStack) s_stack2[sp][tid] = first0 ? N.b.w : N.b.z;
+                        ++sp;
+                        ref = first0 ? N.b.z : N.b.w;
+                    } else if (h0 | h1) {
+                        ref = h0 ? N.b.z : N.b.w;
+                    } else {
+                        ref = pop_ref(s_stack2, sp, tid);
+                    }
+                    if (ref == kDone) phase = kDoneWalk;
+                }
+                if (leaves_now && at_leaf) {
+                    const uint32_t first = ref & kBvhLeafFirst, count = (ref >> kBvhLeafCountShift) & 15u;
+                    for (uint32_t k = 0; k < count; ++k)
+                        fast_leaf_item(sc, sc.bvh_fast[first + k], ps.o, ps.d, inv, noi, kTMin, closest, best);
+                    ref = pop_ref(s_stack2, sp, tid);
+                    if (ref == kDone) phase = kDoneWalk;
                 }
             }
         }

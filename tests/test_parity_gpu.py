@@ -168,15 +168,21 @@ def test_bvh_and_linear_scan_agree_at_scale(gpu_ctx):
     assert lin["hit"].mean() > 0.3
 
 
+@pytest.mark.parametrize("tree", ["eight-wide", "two-child"])
 @pytest.mark.parametrize("name,w,h,spp", [("random_field", 96, 54, 8), ("bvh_stress_2000", 64, 36, 4),
                                           ("cornell_extra", 64, 36, 8), ("textured", 64, 36, 4)])
-def test_fast_bvh_kernel_follows_the_paths_of_the_fast_scan(gpu_ctx, name, w, h, spp):
+def test_fast_bvh_kernel_follows_the_paths_of_the_fast_scan(gpu_ctx, monkeypatch, name, w, h, spp, tree):
     """Fast mode renders BVH scenes with a kernel of its own (traversal decoupled from shading, its
     own node / leaf loop).  Sample for sample it must follow the paths the fast linear-scan kernel
     follows: same random stream, same shading code, only the way the nearest hit is found differs
     (and the rounding of leaf tests and camera rays, which moves a path only where two candidates
     lie within rounding of each other).  A subtree skipped wrongly shows up as a different segment
-    count or radiance of that sample."""
+    count or radiance of that sample.  The kernel walks the eight-wide tree, or - for a tree deeper
+    than its stack, forced here through the environment - the two-child tree: both loops are checked."""
+    if tree == "two-child":
+        monkeypatch.setenv("RTX_WIDE_MIN_ITEMS", "1000000000")  # read by rtx_upload_scene
+    else:
+        monkeypatch.delenv("RTX_WIDE_MIN_ITEMS", raising=False)
     scene = api.HostScene(name, w, h)
     p = gpu_ctx.params(w, h, 3, spp, mode=api.RTX_MODE_FAST, seed=31)
     gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
