@@ -186,15 +186,27 @@ def launch_ranks(args) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode]
-    deadline = time.time() + 120.0
-    for p in procs[1:]:
-        try:
-            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            codes.append(p.wait())
+    # rank 0's stdout is drained by a thread while all ranks are watched: a rank that dies takes the
+    # others down with it at once (they would otherwise wait in the rendezvous or a collective
+    # until its timeout)
+    import threading
+
+    captured = []
+    reader = threading.Thread(target=lambda: captured.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes):
+            for p in procs:  # exactly the children started above
+                if p.poll() is None:
+                    p.kill()
+            codes = [p.wait() if c is None else c for p, c in zip(procs, codes)]
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10.0)
+    out = captured[0] if captured else b""
     # rank 0's JSON line goes to stdout; anything else a library printed there (gloo and RCCL
     # announce themselves on stdout) goes to stderr, so that stdout stays the one line
     for line in out.decode(errors="replace").splitlines():

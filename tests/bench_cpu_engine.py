@@ -20,4 +20,8 @@ class _Engine:
 
 
 def make_engine(scene: str, width: int, height: int, mode: str):
+    import os
+
+    if os.environ.get("BENCH_ENGINE_FAIL_RANK") == os.environ.get("RANK", "0"):
+        raise SystemExit(3)  # a rank that dies before the rendezvous (tests/test_bench_launch.py)
     return _Engine(scene, width, height, mode)

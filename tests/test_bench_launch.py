@@ -51,6 +51,19 @@ def test_gpus_2_starts_two_ranks_and_sums_their_work(tmp_path):
     assert abs(j2["roofline"]["rays_per_launch"] * 2 * j2["steps"] / rays2 - 1) < 0.2
 
 
+def test_a_rank_that_dies_ends_the_run_at_once():
+    """Rank 1 exits before the rendezvous; rank 0 would wait there for minutes.  The parent must
+    stop the others and fail."""
+    import time
+
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--spp-per-step", "1"] + COMMON, env={"BENCH_ENGINE_FAIL_RANK": "1"}, check=False)
+    assert r.returncode == 1 and "ranks failed" in r.stderr, r.stderr[-1000:]
+    assert "(1, 3)" in r.stderr  # rank 1, its exit code
+    assert time.time() - t0 < 60.0
+    assert not any(ln.lstrip().startswith("{") for ln in r.stdout.splitlines())
+
+
 def test_world_size_must_match_gpus():
     r = _run(["--gpus", "2", "--spp-per-step", "1"] + COMMON, env={"WORLD_SIZE": "1", "RANK": "0"}, check=False)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
