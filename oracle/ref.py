@@ -34,6 +34,10 @@ def load() -> C.CDLL:
         lib.ref_resolve.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         lib.ref_write_bmp.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
         lib.ref_write_bmp.restype = C.c_int
+        lib.ref_load_image.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+        lib.ref_load_image.restype = C.c_int
+        lib.ref_write_jpg.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        lib.ref_write_jpg.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -131,6 +135,27 @@ def write_bmp(path, rgb8):
     a = np.ascontiguousarray(rgb8, np.uint8)
     h, w, _ = a.shape
     return lib.ref_write_bmp(path.encode(), w, h, a.ctypes.data)
+
+
+def load_image(path):
+    """The texels the reference's ImageTexture holds for `path` (stb_image, ImageTexture.h:9):
+    (h, w, channels) uint8, or None if the file cannot be read."""
+    lib = load()
+    w, h = C.c_int(0), C.c_int(0)
+    n = lib.ref_load_image(str(path).encode(), C.byref(w), C.byref(h), None, 0)
+    if n == 0:
+        return None
+    out = np.zeros((h.value, w.value, n), np.uint8)
+    lib.ref_load_image(str(path).encode(), C.byref(w), C.byref(h), out.ctypes.data, out.nbytes)
+    return out
+
+
+def write_jpg(path, pixels, quality):
+    """A JPEG of an (h, w, 1 | 3) uint8 image through the encoder the reference vendors."""
+    lib = load()
+    a = np.ascontiguousarray(pixels, np.uint8)
+    h, w, n = a.shape
+    return lib.ref_write_jpg(str(path).encode(), w, h, n, a.ctypes.data, int(quality))
 
 
 def background_sky(dirs):

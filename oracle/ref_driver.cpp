@@ -274,6 +274,24 @@ int ref_write_bmp(const char* path, int w, int h, const uint8_t* rgb) {
     return stbi_write_bmp(path, w, h, 3, rgb);
 }
 
+/* The texels the reference's ImageTexture holds for a file: the loader call of ImageTexture.h:9
+ * (stbi_load with no forced channel count).  Returns the channel count, 0 if the file cannot be
+ * read; `out` (may be null: query of the size) receives w * h * channels bytes. */
+int ref_load_image(const char* path, int* w, int* h, uint8_t* out, size_t capacity) {
+    int n = 0;
+    unsigned char* texels = stbi_load(path, w, h, &n, 0);
+    if (!texels) return 0;
+    const size_t bytes = size_t(*w) * size_t(*h) * size_t(n);
+    if (out && bytes <= capacity) memcpy(out, texels, bytes);
+    stbi_image_free(texels);
+    return n;
+}
+
+/* A JPEG file of an RGB image, written by the encoder the reference vendors beside its BMP
+ * writer (external/stb/stb_image_write.h): test input for the product's JPEG decoder. */
+int ref_write_jpg(const char* path, int w, int h, int channels, const uint8_t* pixels, int quality) {
+    return stbi_write_jpg(path, w, h, channels, pixels, quality);
+}
 
 /* Scene::backgroundSky (Scene.h:24-28) of n directions: the reference defines the gradient but
  * its color() never calls it, so it is pinned function by function. */

@@ -103,7 +103,7 @@ RTX_NOALLOC_MAX_PIXELS = 1 << 21
 RTXH_SYMBOLS = (
     "rtxh_last_error", "rtxh_scene_create", "rtxh_scene_view", "rtxh_scene_destroy",
     "rtxh_image_write", "rtxh_resolve", "rtxh_write_bmp", "rtxh_render_to_bmp",
-    "rtxh_render_to_bmp_multi",
+    "rtxh_render_to_bmp_multi", "rtxh_load_image",
 )
 
 
@@ -198,6 +198,8 @@ def load_libhost() -> C.CDLL:
         lib.rtxh_resolve.restype = None
         lib.rtxh_write_bmp.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
         lib.rtxh_write_bmp.restype = C.c_int
+        lib.rtxh_load_image.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+        lib.rtxh_load_image.restype = C.c_int
         lib.rtxh_render_to_bmp.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_uint64, C.c_int, C.POINTER(C.c_ulonglong),
                                            C.POINTER(C.c_double)]
@@ -396,6 +398,17 @@ def resolve_host(sum_rgb: np.ndarray, ns: int) -> np.ndarray:
     h, w, _ = a.shape
     out = np.zeros((h, w, 3), np.uint8)
     lib.rtxh_resolve(w, h, ns, a.ctypes.data, out.ctypes.data)
+    return out
+
+
+def load_image(path: str) -> np.ndarray:
+    """The texels ImageTexture(path) holds: (h, w, 3) uint8, rows top-down."""
+    lib = load_libhost()
+    w, h = C.c_int(0), C.c_int(0)
+    if not lib.rtxh_load_image(str(path).encode(), C.byref(w), C.byref(h), None, 0):
+        raise ValueError(lib.rtxh_last_error().decode())
+    out = np.zeros((h.value, w.value, 3), np.uint8)
+    lib.rtxh_load_image(str(path).encode(), C.byref(w), C.byref(h), out.ctypes.data, out.nbytes)
     return out
 
 

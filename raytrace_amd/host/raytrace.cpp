@@ -3,6 +3,8 @@
 // writer and Scene::render(), which drives the GPU through the C ABI.
 #include "raytrace.h"
 
+#include "image_decode.h"
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -313,10 +315,12 @@ ImageTexture::ImageTexture(const char* name) : m_name(name ? name : "") {
     size_t n;
     while ((n = std::fread(buf, 1, sizeof buf, fp)) > 0) data.insert(data.end(), buf, buf + n);
     std::fclose(fp);
-    if (!load_bmp(data, m_width, m_height, m_texels) && !load_ppm(data, m_width, m_height, m_texels)) {
-        m_width = m_height = 0;
-        m_texels.clear();
-    }
+    if (load_bmp(data, m_width, m_height, m_texels) || load_ppm(data, m_width, m_height, m_texels)) return;
+    if (data.size() >= 2 && data[0] == 0xFF && data[1] == 0xD8 &&
+        detail::load_jpeg(data, m_width, m_height, m_texels, m_error))
+        return;
+    m_width = m_height = 0;
+    m_texels.clear();
 }
 
 ImageTexture::ImageTexture(int width, int height, const unsigned char* rgb)
@@ -324,7 +328,8 @@ ImageTexture::ImageTexture(int width, int height, const unsigned char* rgb)
 
 uint32_t ImageTexture::flatten(FlatScene& f) const {
     if (!loaded()) {
-        f.fail("ImageTexture '" + m_name + "': cannot read (24-bit BMP and binary PPM are supported)");
+        f.fail("ImageTexture '" + m_name + "': cannot read (24-bit BMP, binary PPM and sequential JPEG are supported)" +
+               (m_error.empty() ? std::string() : ": " + m_error));
         return 0;
     }
     return f.new_image_texture(m_width, m_height, m_texels.data());

@@ -211,11 +211,13 @@ public:
     int width() const { return m_width; }
     int height() const { return m_height; }
     bool loaded() const { return !m_texels.empty(); }
+    const unsigned char* texels() const { return m_texels.data(); }  // rows top-down, RGB
+    const std::string& error() const { return m_error; }             // why a JPEG file was refused
 
 private:
     int m_width = 0, m_height = 0;
     std::vector<unsigned char> m_texels;  // rows top-down, RGB
-    std::string m_name;
+    std::string m_name, m_error;
 };
 
 // ---------------------------------------------------------------------------

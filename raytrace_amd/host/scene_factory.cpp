@@ -102,6 +102,22 @@ int rtxh_write_bmp(const char* path, int w, int h, const uint8_t* rgb) {
     return img.save_bmp(path) ? 1 : 0;
 }
 
+// The texels rt::ImageTexture holds for a file (24-bit BMP, binary PPM, sequential JPEG): RGB,
+// rows top-down.  Returns 1 and the size (and the texels, if `out` holds w * h * 3 bytes), 0 and
+// rtxh_last_error() if the file cannot be decoded.
+int rtxh_load_image(const char* path, int* w, int* h, uint8_t* out, size_t capacity) {
+    ImageTexture tex(path);
+    if (!tex.loaded()) {
+        g_error = std::string("cannot decode '") + (path ? path : "") + "'" + (tex.error().empty() ? "" : ": " + tex.error());
+        return 0;
+    }
+    *w = tex.width();
+    *h = tex.height();
+    const size_t bytes = (size_t)tex.width() * tex.height() * 3;
+    if (out && bytes <= capacity) std::memcpy(out, tex.texels(), bytes);
+    return 1;
+}
+
 // The whole Scene::render() path: build, flatten, GPU render, filters, BMP.
 int rtxh_render_to_bmp(const char* name, const char* path, int w, int h, int spp, int deterministic,
                        uint64_t seed, int device, unsigned long long* rays, double* seconds) {

@@ -5,7 +5,7 @@ oracle/Makefile, fed the counter-based stream of include/rtx_det.h).
 
 Run from the repository root in a container that holds /root/reference:
     make -C oracle && python tests/golden/make_golden.py [section ...]
-(sections: texture samples hits misc pieces lights scatter flops gt gt_ref resolve; default all but "resolve_exhaustive"; "samples:textured" and
+(sections: texture samples hits misc pieces lights scatter flops gt gt_ref resolve jpeg; default all but "resolve_exhaustive"; "samples:textured" and
 "hits:textured" restrict a section to one scene).
 The reference has no fixtures of its own for this path, so these files are what pins
 the CPU restatement (and through it the GPU path) wherever the reference is absent.
@@ -33,6 +33,7 @@ SAMPLE_CASES = [  # scene, w, h, spp_begin, spp, seed
     ("random_field", 32, 18, 0, 4, 7),
     ("bvh_stress_500", 24, 14, 0, 2, 7),
     ("textured", 48, 27, 0, 8, 7),
+    ("textured_jpeg", 48, 27, 0, 8, 7),  # the reference's own JPEG asset: both sides have to decode it alike
     ("sky_spheres", 48, 27, 0, 8, 7),  # no light shape + sky: from the CPU restatement (see RESTATEMENT_ONLY)
     ("sky_sphere_lit", 48, 27, 0, 8, 7),  # the sky gradient as an emitting sphere around the scene: the REFERENCE renders it
     ("cornell_light_tree", 48, 27, 0, 8, 7),   # nested light lists, XY rect / wrapped shapes with the default density
@@ -92,6 +93,7 @@ def main(argv):
         return section in sections or (scene is not None and f"{section}:{scene}" in sections)
 
     os.environ["RTX_TEXTURE"] = TEXTURE
+    os.environ["RTX_TEXTURE_JPEG"] = "/root/reference/Raytrace_C++/Asset/Texture/field001.jpg"
     if want("texture"):
         write_texture_fixture()
     index_path = os.path.join(HERE, "index.json")
@@ -145,6 +147,41 @@ def main(argv):
                 ground_truth_ref(*spec)
     if want("resolve") or want("resolve_exhaustive"):
         resolve_thresholds(exhaustive=want("resolve_exhaustive"))
+    if want("jpeg"):
+        jpeg_vectors()
+
+
+def jpeg_vectors():
+    """JPEG files and the texels the reference's loader (stb_image through ImageTexture.h:9's
+    call) makes of them: the reference's own texture asset, files from the encoder it vendors
+    (4:2:0 up to quality 90, 4:4:4 above), and the layouts of tests/golden/jpeg_cases.py."""
+    import tempfile
+
+    sys.path.insert(0, HERE)
+    import jpeg_cases
+
+    files = {}
+    asset = "/root/reference/Raytrace_C++/Asset/Texture/field001.jpg"
+    files["asset_field001"] = open(asset, "rb").read()
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (w, h, quality) in {"stbw_q50_45x37": (45, 37, 50), "stbw_q90_16x16": (16, 16, 90),
+                                      "stbw_q95_33x20": (33, 20, 95), "stbw_q100_8x24": (8, 24, 100)}.items():
+            path = os.path.join(tmp, name + ".jpg")
+            assert ref.write_jpg(path, jpeg_cases.test_image(w, h, quality), quality)
+            files[name] = open(path, "rb").read()
+        for name, (w, h, kw) in jpeg_cases.CASES.items():
+            files[name] = jpeg_cases.encode(jpeg_cases.test_image(w, h, len(name)), **kw)
+        out = {}
+        for name, data in files.items():
+            path = os.path.join(tmp, name + ".jpg")
+            with open(path, "wb") as f:
+                f.write(data)
+            texels = ref.load_image(path)
+            assert texels is not None, name
+            out[name + "_file"] = np.frombuffer(data, np.uint8)
+            out[name + "_texels"] = texels
+            print("jpeg", name, len(data), "bytes ->", texels.shape)
+    np.savez_compressed(os.path.join(HERE, "jpeg_cases.npz"), **out)
 
 
 LIGHT_SCENES = ("cornell", "small", "cornell_light_tree", "cornell_many_lights")

@@ -173,6 +173,58 @@ def test_image_texture_ppm_and_padded_bmp(tmp_path, monkeypatch):
         assert np.array_equal(_textured_texels(tmp_path / name, monkeypatch), img), name
 
 
+def _jpeg_cases():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "jpeg_cases.npz"))
+    return g, sorted(k[:-5] for k in g.files if k.endswith("_file"))
+
+
+@pytest.mark.parametrize("name", _jpeg_cases()[1])
+def test_image_texture_jpeg_decoder_returns_the_references_texels(tmp_path, name):
+    """The reference decodes its texture asset with the stb_image it vendors (ImageTexture.h:9); a
+    JPEG decoder is free in its rounding, so the product's decoder has to reproduce THAT decoder's
+    texels.  The fixture holds files (the reference's asset, files from the encoder it vendors,
+    and the layouts of tests/golden/jpeg_cases.py: 4:2:2, 4:4:0, 4:1:1, restart intervals, one
+    scan per component, 16-bit quantisers, grey scale, RGB component ids) and what the
+    reference's loader returned for each."""
+    g, _ = _jpeg_cases()
+    path = tmp_path / (name + ".jpg")
+    path.write_bytes(g[name + "_file"].tobytes())
+    want = g[name + "_texels"]
+    if want.shape[2] == 1:  # grey scale: the product hands the flattener RGB
+        want = np.repeat(want, 3, axis=2)
+    got = api.load_image(str(path))
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_jpeg_texture_reaches_the_flattened_scene(tmp_path, monkeypatch):
+    g, _ = _jpeg_cases()
+    path = tmp_path / "field001.jpg"
+    path.write_bytes(g["asset_field001_file"].tobytes())
+    got = _textured_texels(path, monkeypatch)  # through ImageTexture and the scene flattener
+    assert got.shape == (160, 160, 3)
+    assert np.array_equal(got, g["asset_field001_texels"])
+
+
+def test_unsupported_and_damaged_jpeg_files_are_refused_with_a_reason(tmp_path):
+    g, _ = _jpeg_cases()
+    data = bytearray(g["s420_57x35_file"].tobytes())
+    sof = data.find(b"\xFF\xC0")
+    data[sof + 1] = 0xC2  # claims to be progressive
+    (tmp_path / "p.jpg").write_bytes(bytes(data))
+    with pytest.raises(ValueError, match="progressive"):
+        api.load_image(str(tmp_path / "p.jpg"))
+    whole = g["s420_57x35_file"].tobytes()
+    (tmp_path / "cut.jpg").write_bytes(whole[:200])  # ends inside the tables
+    with pytest.raises(ValueError):
+        api.load_image(str(tmp_path / "cut.jpg"))
+    (tmp_path / "cut2.jpg").write_bytes(whole[:-300])  # ends inside the scan: decodes what is there
+    try:
+        assert api.load_image(str(tmp_path / "cut2.jpg")).shape == (35, 57, 3)
+    except ValueError:
+        pass
+
+
 def test_missing_texture_file_is_an_error(tmp_path, monkeypatch):
     monkeypatch.setenv("RTX_TEXTURE", str(tmp_path / "nope.bmp"))
     with pytest.raises(ValueError):

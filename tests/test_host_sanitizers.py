@@ -2,7 +2,8 @@
 the host image pipeline (raytrace_amd/host/raytrace.cpp, scene_factory.cpp), driven by
 tests/flatten_check.cpp over every named scene.  The tree builders have their own sanitizer run
 in tests/test_bvh_builder.py.  Device code cannot be sanitized on this pool; these are the parts of
-the library that run on the host for every scene upload."""
+the library that run on the host for every scene upload.  The JPEG decoder behind ImageTexture
+reads files from outside: it is run on damaged files as well."""
 import os
 import subprocess
 
@@ -17,7 +18,8 @@ def test_flattener_and_image_pipeline_are_clean_under_asan_ubsan(tmp_path):
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
            "-fno-sanitize-recover=undefined", "-I" + os.path.join(ROOT, "include"), "-I" + host,
            os.path.join(ROOT, "tests", "flatten_check.cpp"), os.path.join(host, "raytrace.cpp"),
-           os.path.join(host, "scene_factory.cpp"), "-L" + os.path.join(ROOT, "raytrace_amd"), "-lrtx",
+           os.path.join(host, "scene_factory.cpp"), os.path.join(host, "jpeg_baseline.cpp"),
+           "-L" + os.path.join(ROOT, "raytrace_amd"), "-lrtx",
            "-Wl,-rpath," + os.path.join(ROOT, "raytrace_amd"), "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -27,3 +29,27 @@ def test_flattener_and_image_pipeline_are_clean_under_asan_ubsan(tmp_path):
     r = subprocess.run([exe, str(tmp_path / "o.bmp")], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-3000:]
     assert os.path.getsize(str(tmp_path / "o.bmp")) == 54 + 5 * 24  # 7 pixels * 3 bytes padded to 24 per row
+
+
+def test_jpeg_decoder_survives_damaged_files_under_asan_ubsan(tmp_path):
+    """tests/jpeg_check.cpp: every fixture file intact, then 3 000 damaged copies of each."""
+    import numpy as np
+
+    exe = str(tmp_path / "jpeg_check")
+    host = os.path.join(ROOT, "raytrace_amd", "host")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-I" + host, os.path.join(ROOT, "tests", "jpeg_check.cpp"), os.path.join(host, "jpeg_baseline.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "jpeg_cases.npz"))
+    files = []
+    for key in g.files:
+        if key.endswith("_file"):
+            files.append(str(tmp_path / (key[:-5] + ".jpg")))
+            with open(files[-1], "wb") as f:
+                f.write(g[key].tobytes())
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-3000:]
+    decoded, refused = (int(x) for x in r.stdout.split()[1:3])
+    assert decoded > 1000 and refused > 1000  # both outcomes were exercised

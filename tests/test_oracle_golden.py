@@ -246,3 +246,17 @@ def test_material_scatter_functions_match_the_reference():
     assert 0 < g["diffuse_light_emitted"].any(axis=1).sum() < g["d"].shape[0]
     assert g["diffuse_light_ok"].sum() == 0 and g["lambertian_ok"].all() and g["dielectric15_ok"].all()
     assert (g["lambertian_spdf"] > 0).any() and (g["lambertian_spdf"] == 0).any()
+
+
+def test_jpeg_fixtures_are_what_the_references_loader_returns(tmp_path):
+    """jpeg_cases.npz against the live reference build: the stored texels are stbi_load's."""
+    if not ref.available():
+        pytest.skip("oracle/_ref is not built")
+    g = util.load_golden("jpeg_cases")
+    names = sorted(k[:-5] for k in g.files if k.endswith("_file"))
+    assert "asset_field001" in names and len(names) >= 20
+    for name in names:
+        path = tmp_path / (name + ".jpg")
+        path.write_bytes(g[name + "_file"].tobytes())
+        got = ref.load_image(path)
+        assert got is not None and np.array_equal(got, g[name + "_texels"]), name
