@@ -29,7 +29,10 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--spp-per-step", type=int, default=256)
-    ap.add_argument("--gt-spp", type=int, default=65536)
+    ap.add_argument("--gt-spp", type=int, default=262144,
+                    help="per quarter-resolution pixel; the final frame has 16 x steps x spp-per-step samples per "
+                         "such pixel, so the default equals the final frame's count: the RMSE floor it leaves is "
+                         "stated in the summary")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "progressive"))
     ap.add_argument("--previews", default="1,4,16,64")
     ap.add_argument("--checkpoint", default="", help="npz file: resume from it if present, rewrite it as the run goes")
@@ -52,9 +55,12 @@ def main():
     ctx.upload(api.HostScene(args.scene, gw, gh), api.RTX_ACCEL_AUTO)
     gt = torch.zeros((gh, gw, 3), dtype=torch.float32, device=dev)
     t0 = time.perf_counter()
-    ctx.render_device(ctx.params(gw, gh, 1 << 24, args.gt_spp, mode=api.RTX_MODE_DETERMINISTIC, seed=4242),
-                      gt.data_ptr(), 0, stream.cuda_stream)
-    torch.cuda.synchronize(dev)
+    chunk = 16384  # launches of a second or two each
+    for begin in range(0, args.gt_spp, chunk):
+        ctx.render_device(ctx.params(gw, gh, (1 << 24) + begin, min(chunk, args.gt_spp - begin),
+                                     mode=api.RTX_MODE_DETERMINISTIC, seed=4242, accumulate=True),
+                          gt.data_ptr(), 0, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
     gt = torch.clamp(gt / args.gt_spp, 0.0, 1.0)  # the 8-bit image clamps too (TonemapFilter.h:8-10)
     print(json.dumps({"ground_truth": f"{gw}x{gh}, {args.gt_spp} spp, deterministic, seed 4242",
                       "seconds": time.perf_counter() - t0}), flush=True)
@@ -99,9 +105,25 @@ def main():
         return
     first, last = rows[0], rows[-1]
     slope = np.log(last["rmse"] / first["rmse"]) / np.log(last["spp"] / first["spp"]) if len(rows) > 1 else float("nan")
+    # model: rmse^2(n) = A / n + F, F = the ground truth's own variance (it does not shrink with n).
+    # A and F from the first and the last step; the slope of the part that does shrink is then
+    # checked at the middle of the run (-0.5 for a Monte Carlo mean).
+    floor = slope_mc = float("nan")
+    if len(rows) > 2:
+        n1, n2 = first["spp"], last["spp"]
+        A = (first["rmse"] ** 2 - last["rmse"] ** 2) / (1.0 / n1 - 1.0 / n2)
+        F = first["rmse"] ** 2 - A / n1
+        floor = float(np.sqrt(max(F, 0.0)))
+        mid = rows[len(rows) // 8]
+        shrinking = mid["rmse"] ** 2 - F
+        if shrinking > 0 and first["rmse"] ** 2 - F > 0 and mid["spp"] != n1:
+            slope_mc = float(0.5 * np.log(shrinking / (first["rmse"] ** 2 - F)) / np.log(mid["spp"] / n1))
     print(json.dumps({"summary": True, "scene": args.scene, "width": w, "height": h, "steps": args.steps,
                       "spp_per_step": args.spp_per_step, "mean_grays_per_s": float(np.mean([r["grays_per_s"] for r in rows])),
-                      "rmse_first": first["rmse"], "rmse_last": last["rmse"], "loglog_slope": float(slope)}), flush=True)
+                      "rmse_first": first["rmse"], "rmse_last": last["rmse"], "loglog_slope": float(slope),
+                      "ground_truth_noise_floor_rmse": floor, "loglog_slope_above_floor": slope_mc,
+                      "ground_truth_spp_per_block": args.gt_spp,
+                      "final_frame_samples_per_block": 16 * last["spp"]}), flush=True)
 
 
 if __name__ == "__main__":
