@@ -357,8 +357,6 @@ void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rt
     sr.push_back(sr.back());  // readable pad record
 }
 
-// Fast-mode leaf records of the BVH items (groups in leaf order) and the hit-completion table
-// in their slot order.
 // Scenes with fewer tree items than this are traced through the two-child tree in fast mode.  0: the
 // eight-wide tree always.  Measured at 1080p (wide against two-child, Grays/s): 200 items 45.7 / 45.6,
 // 500 items 37.4 / 35.5, 1 000 items 29.9 / 28.8, 2 000 items 25.0 / 23.3, 100 000 items 6.42 / 5.93; only
@@ -369,6 +367,8 @@ size_t wide_min_items() {
     return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0;
 }
 
+// Fast-mode leaf records of the BVH items (groups in leaf order) and the hit-completion table
+// in their slot order.
 void build_bvh_fast_items(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::PrimInfo>& info,
                           const std::vector<rtxd::Group>& items, const std::vector<rtxd::Step>& steps,
                           std::vector<rtxd::BvhFastItem>& out, std::vector<rtxd::BvhMap>& maps,
