@@ -170,7 +170,11 @@ def test_bvh_and_linear_scan_agree_at_scale(gpu_ctx):
 
 @pytest.mark.parametrize("tree", ["eight-wide", "two-child"])
 @pytest.mark.parametrize("name,w,h,spp", [("random_field", 96, 54, 8), ("bvh_stress_2000", 64, 36, 4),
-                                          ("cornell_extra", 64, 36, 8), ("textured", 64, 36, 4)])
+                                          ("cornell_extra", 64, 36, 8), ("textured", 64, 36, 4),
+                                          # ragged frames (tiles that hang over the edge, draws that fall
+                                          # outside), odd sample counts, a single pixel
+                                          ("random_field", 57, 35, 3), ("bvh_stress_500", 5, 3, 7),
+                                          ("bvh_stress_500", 1, 1, 33), ("random_field", 130, 2, 5)])
 def test_fast_bvh_kernel_follows_the_paths_of_the_fast_scan(gpu_ctx, monkeypatch, name, w, h, spp, tree):
     """Fast mode renders BVH scenes with a kernel of its own (traversal decoupled from shading, its
     own node / leaf loop).  Sample for sample it must follow the paths the fast linear-scan kernel
@@ -193,12 +197,17 @@ def test_fast_bvh_kernel_follows_the_paths_of_the_fast_scan(gpu_ctx, monkeypatch
     bvh_rgb, bvh_seg = gpu_ctx.render_samples(p)
     bvh_sum, bvh_rays = gpu_ctx.render(p)
     same = bvh_seg == lin_seg
-    assert same.mean() >= 0.995, same.mean()
+    allowed = max(2, int(0.005 * same.size))  # samples whose path may differ (tiny frames: two)
+    assert (~same).sum() <= allowed, ((~same).sum(), same.size)
     # where the path is the same, so is its radiance (up to the rounding of hit points)
     close = np.isclose(bvh_rgb, lin_rgb, rtol=2e-2, atol=1e-3).all(axis=-1)
-    assert (close | ~same).mean() >= 0.995, (close | ~same).mean()
-    assert abs(float(bvh_rgb.sum()) / float(lin_rgb.sum()) - 1) < (1e-3 if same.mean() > 0.9995 else 2e-2)
-    assert abs(bvh_rays / lin_rays - 1) < 2e-3
+    assert (~(close | ~same)).sum() <= allowed, (~(close | ~same)).sum()
+    if same.all():
+        assert abs(float(bvh_rgb.sum()) / float(lin_rgb.sum()) - 1) < 1e-3
+        assert bvh_rays == lin_rays
+    elif same.size >= 4096:
+        assert abs(float(bvh_rgb.sum()) / float(lin_rgb.sum()) - 1) < 2e-2
+        assert abs(bvh_rays / lin_rays - 1) < 2e-3
     # the frame the kernel accumulates is the sum of the samples it reports
     flipped = bvh_rgb.reshape(h, w, spp, 3).sum(axis=2)[::-1]
     assert np.allclose(bvh_sum, flipped, rtol=1e-4, atol=1e-5)
