@@ -1948,6 +1948,8 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     const uint4* p = reinterpret_cast<const uint4*>(sc.bvh_wide + node);
                     const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
                     const uint32_t hitmask = wide_node_hits(n0, n1, n2, n3, n4, inv, noi, oct_inv4, kTMin, closest);
+                    RTX_STAT(11, (uint32_t)__popcll(__ballot(hitmask == 0u)));  // [11] node steps that met no child
+                    RTX_STAT(10, (uint32_t)__popcll(__ballot(hitmask == 0u && best != kNone)));  // [10] ... with a hit in hand
                     ng_base = n1.x;
                     ng_bits = (hitmask & 0xff000000u) | (n0.w >> 24);
                     ig_base = n1.y;
