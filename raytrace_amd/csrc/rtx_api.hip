@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -357,13 +358,23 @@ void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rt
     sr.push_back(sr.back());  // readable pad record
 }
 
-// Scenes with fewer tree items than this are traced through the two-child tree in fast mode.  0: the
-// eight-wide tree always.  Measured at 1080p (wide against two-child, Grays/s): 200 items 45.7 / 45.6,
-// 500 items 37.4 / 35.5, 1 000 items 29.9 / 28.8, 2 000 items 25.0 / 23.3, 100 000 items 6.42 / 5.93; only
-// the 487-sphere field prefers the two-child tree (21.0 / 21.7), so no item count separates the two.
-// RTX_WIDE_MIN_ITEMS overrides, for measurements.
+// Which tree the fast trace kernel walks.  A step down the eight-wide tree costs about three times the
+// instructions of a step down the two-child tree, so it pays when it saves enough steps: by the
+// surface-area estimates of the builder (expected node visits of a ray through the root box), the
+// wide tree is used when the two-child tree needs at least kWideMinVisitRatio times its visits.
+// Measured at 1080p, wide against two-child, Grays/s (ratio of the estimates): 487-sphere field 21.0 /
+// 21.7 (2.52); 200 / 500 / 1 000 / 2 000 / 20 000 / 100 000 items in a slab 45.7 / 45.6 (2.65), 37.4 / 35.5
+// (2.74), 29.9 / 28.8 (2.83), 25.0 / 23.3 (2.86), 11.6 / 10.6 (2.99), 6.42 / 5.93 (3.04); a 12-item Cornell
+// box 19.4 / 17.7 (4.30), one with 104 lights 9.6 / 8.6 (4.45).
+// RTX_WIDE_MIN_RATIO and RTX_WIDE_MIN_ITEMS (scenes with fewer tree items walk the two-child tree)
+// override, for measurements and tests; RTX_TREE_STATS prints the estimates.
+constexpr double kWideMinVisitRatio = 2.6;
+double wide_min_ratio() {
+    const char* e = std::getenv("RTX_WIDE_MIN_RATIO");  // read at every upload: tests switch it
+    return e ? std::atof(e) : kWideMinVisitRatio;
+}
 size_t wide_min_items() {
-    const char* e = std::getenv("RTX_WIDE_MIN_ITEMS");  // read at every upload: tests switch it
+    const char* e = std::getenv("RTX_WIDE_MIN_ITEMS");
     return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0;
 }
 
@@ -700,10 +711,15 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
         if (tree.depth + 1 > rtxd::kBvhStackEntries)
             return fail(RTX_ERR_TOO_LARGE, "BVH is deeper than the traversal stack");
         build_bvh_fast_items(prims, info, items, steps, fast_items, fast_maps, scan_info, scan_orig);
+        if (std::getenv("RTX_TREE_STATS"))
+            std::fprintf(stderr, "rtx tree: %zu items, %zu two-child nodes (%.2f visits), %zu wide nodes (%.2f visits), ratio %.2f\n",
+                         items.size(), tree.nodes.size(), tree.visits_two_child, tree.wide.size(), tree.visits_wide,
+                         tree.visits_wide > 0.0 ? tree.visits_two_child / tree.visits_wide : 0.0);
         // the eight-wide tree of the fast trace kernel reads the leaf records in its own order; a
-        // tree deeper than that kernel's stack, or a small one, is rendered through the two-child
-        // tree instead
-        if (tree.wide_depth <= rtxd::kWideStackEntries && items.size() >= wide_min_items()) {
+        // tree deeper than that kernel's stack, or one that saves too few steps (see
+        // kWideMinVisitRatio), is rendered through the two-child tree instead
+        const bool wide_pays = tree.visits_wide > 0.0 && tree.visits_two_child >= wide_min_ratio() * tree.visits_wide;
+        if (tree.wide_depth <= rtxd::kWideStackEntries && items.size() >= wide_min_items() && wide_pays) {
             wide_items.reserve(tree.wide_order.size());
             for (uint32_t k : tree.wide_order) wide_items.push_back(fast_items[k]);
         } else {

@@ -242,6 +242,7 @@ void build_wide(const std::vector<TmpNode>& nodes, Tree& out) {
     out.wide.clear();
     out.wide_order.clear();
     out.wide_depth = 0;
+    out.wide_area_sum = 0.0;
     out.wide.emplace_back();
     std::vector<Pending> queue;
     queue.push_back(Pending{0, 0, 1});
@@ -258,6 +259,7 @@ void build_wide(const std::vector<TmpNode>& nodes, Tree& out) {
         }
         Box box;
         for (uint32_t k : kids) box.add(nodes[k].box);
+        out.wide_area_sum += box.area();
         // slots: child c goes where (centre_c - centre_node) . (+-1, +-1, +-1)_slot is largest, greedily
         double centre[3];
         for (int a = 0; a < 3; ++a) centre[a] = 0.5 * (box.lo[a] + box.hi[a]);
@@ -502,6 +504,14 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
     }
     static_assert(kLeafItems <= 3, "a wide node's meta byte counts a leaf's items in unary, three bits");
     build_wide(nodes, out);
+    {   // expected node visits of a ray through the root box, by the surface-area measure
+        const double root = nodes[0].box.area();
+        double two = 0.0;
+        for (const TmpNode& N : nodes)
+            if (N.count == 0) two += N.box.area();
+        out.visits_two_child = root > 0.0 ? two / root : 0.0;
+        out.visits_wide = root > 0.0 ? out.wide_area_sum / root : 0.0;
+    }
     if (nodes[0].count != 0) {
         // a single leaf: root node with one real child and one empty box
         // (the leaf is then visited twice when the ray meets its box: harmless, a primitive

@@ -37,6 +37,9 @@ struct Tree {
     std::vector<rtxd::WideNode> wide;
     std::vector<uint32_t> wide_order;
     int wide_depth = 0;
+    // surface-area estimates: the inner nodes of the two-child tree / the nodes of the wide tree a
+    // ray through the root box visits on average (sum of node areas over the root's area)
+    double visits_two_child = 0.0, visits_wide = 0.0, wide_area_sum = 0.0;
     float origin[3] = {0, 0, 0};
     float scale[3] = {1, 1, 1};
 };

@@ -187,6 +187,7 @@ def test_fast_bvh_kernel_follows_the_paths_of_the_fast_scan(gpu_ctx, monkeypatch
         monkeypatch.setenv("RTX_WIDE_MIN_ITEMS", "1000000000")  # read by rtx_upload_scene
     else:
         monkeypatch.delenv("RTX_WIDE_MIN_ITEMS", raising=False)
+        monkeypatch.setenv("RTX_WIDE_MIN_RATIO", "0")  # whatever the builder's estimate says
     scene = api.HostScene(name, w, h)
     p = gpu_ctx.params(w, h, 3, spp, mode=api.RTX_MODE_FAST, seed=31)
     gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
