@@ -342,6 +342,11 @@ int main(int argc, char** argv) {
     if (wstack_max > tree.wide_depth) return fail("wide walk: stack deeper than the tree");
     std::printf("wide nodes=%zu depth=%d stack max=%d pairs=%u visited/ray=%.1f\n", tree.wide.size(), tree.wide_depth,
                 wstack_max, wchecked, wvisited / 400.0);
+    // the builder's surface-area estimates, which the upload uses to choose between the two trees: the
+    // root counts once in both, and collapsing a tree cannot add visits
+    if (tree.nodes.size() > 1 && !(tree.visits_wide >= 1.0 - 1e-9 && tree.visits_two_child >= tree.visits_wide - 1e-9))
+        return fail("visit estimates: expected 1 <= wide <= two-child");
+    std::printf("estimated visits two-child=%.2f wide=%.2f\n", tree.visits_two_child, tree.visits_wide);
 
     // ---- light tree: every group as a light leaf, entries = arbitrary distinct numbers ----
     std::vector<uint32_t> entries(groups.size());
