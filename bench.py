@@ -84,51 +84,79 @@ def cpu_baseline(scene: str, w: int, h: int, threads: int, seconds_budget: float
     """The reference tracer itself (oracle/_ref) timed on this host's cores on a bounded sample
     of the same workload; beside it the CPU restatement (no shared_ptr traffic in the hit
     record, so it scales with the cores where the reference does not).  Without oracle/_ref
-    the restatement is the baseline (kind "port")."""
+    the restatement is the baseline (kind "port").
+
+    The sample is the workload's scene and camera at the largest frame and sample count that
+    fit the time budget: the full frame at 1 .. 64 spp where one sample per pixel is affordable
+    (the Cornell box), a frame scaled down in both axes at 1 spp where it is not (the reference
+    has no acceleration structure: a ray of the 100 000-item scene costs it a millisecond)."""
     from oracle import ref, restate
     from raytrace_amd import api
 
-    flat = api.HostScene(scene, w, h)
+    def scene_at(fw, fh):
+        flat = api.HostScene(scene, fw, fh)
+        rs = ref.RefScene(scene, fw, fh) if ref.available() else None
+        return flat, rs
 
-    def run_port(spp, n_threads):
+    def run_port(flat, fw, fh, spp, n_threads):
         t = time.perf_counter()
-        out = restate.render(flat, w, h, 0, spp, seed=0, threads=n_threads)
+        out = restate.render(flat, fw, fh, 0, spp, seed=0, threads=n_threads)
         return time.perf_counter() - t, out["rays"]
 
-    if ref.available():
-        kind = "reference"
-        rs = ref.RefScene(scene, w, h)
+    kind = "reference" if ref.available() else "port"
 
-        def run(spp, n_threads=threads):
-            t = time.perf_counter()
-            out = rs.render(0, spp, seed=0, threads=n_threads)
-            return time.perf_counter() - t, out["rays"]
-    else:
-        kind = "port"
+    def run(flat, rs, fw, fh, spp, n_threads):
+        if rs is None:
+            return run_port(flat, fw, fh, spp, n_threads)
+        t = time.perf_counter()
+        out = rs.render(0, spp, seed=0, threads=n_threads)
+        return time.perf_counter() - t, out["rays"]
 
-        def run(spp, n_threads=threads):
-            return run_port(spp, n_threads)
+    def size_for(samples):
+        """The frame (aspect of the workload's) and sample count for about `samples` samples."""
+        if samples >= w * h:
+            return w, h, int(max(1, min(64, samples / (w * h))))
+        f = max((samples / (w * h)) ** 0.5, 16.0 / w)
+        return max(16, int(w * f)), max(9, int(h * f)), 1
 
-    dt1, rays1 = run(1)
-    spp = int(max(1, min(64, seconds_budget / max(dt1, 1e-3))))
-    dt, rays = (dt1, rays1) if spp == 1 else run(spp)
-    dts, rays_s = run(1, 1)  # one sample per pixel on one core
+    scenes = {}
+
+    def scene_cached(fw, fh):
+        if (fw, fh) not in scenes:
+            scenes[(fw, fh)] = scene_at(fw, fh)
+        return scenes[(fw, fh)]
+
+    def calibrated(budget, n_threads, port=False):
+        """Run at growing sizes - a 16x9 probe, about two seconds, the budget - each sized from the
+        rate of the one before (tiny frames under-report the rate); returns the last run."""
+        fw, fh, spp = 16, 9, 1
+        for target in (None, 2.0, budget):
+            if target is not None:
+                nw, nh, nspp = size_for(rate * target / rays_per_sample)
+                if (nw, nh, nspp) == (fw, fh, spp):
+                    continue
+                fw, fh, spp = nw, nh, nspp
+            flat, rs = scene_cached(fw, fh)
+            dt, rays = run_port(flat, fw, fh, spp, n_threads) if port else run(flat, rs, fw, fh, spp, n_threads)
+            rate, rays_per_sample = rays / max(dt, 1e-6), rays / (fw * fh * spp)
+        return dt, rays, fw, fh, spp
+
+    dt, rays, fw, fh, spp = calibrated(seconds_budget, threads)
+    dts, rays_s, sw, sh, sspp = calibrated(5.0, 1)
     out = {
         "value": rays / dt / 1e6,
         "unit": "Mrays/s",
         "cores": threads,
         "kind": kind,
-        "sample": f"{scene} {w}x{h}, {spp} spp, depth 50, deterministic stream, {dt:.1f} s",
-        "spp_per_s": spp / dt,
+        "sample": f"{scene}, camera of the {w}x{h} frame at {fw}x{fh}, {spp} spp, depth 50, deterministic stream, {dt:.1f} s",
+        "spp_per_s": spp * (fw * fh) / (w * h) / dt,  # in full frames
         "single_core_value": rays_s / dts / 1e6,
-        "single_core_sample": f"1 spp, {dts:.1f} s",
+        "single_core_sample": f"{sw}x{sh}, {sspp} spp, {dts:.1f} s",
     }
     if kind == "reference":
-        dtp1, _ = run_port(1, threads)
-        spp_p = int(max(1, min(64, 5.0 / max(dtp1, 1e-3))))
-        dtp, rays_p = run_port(spp_p, threads)
+        dtp, rays_p, qw, qh, qspp = calibrated(5.0, threads, port=True)
         out["port_value"] = rays_p / dtp / 1e6
-        out["port_sample"] = f"CPU restatement, {threads} threads, {spp_p} spp, {dtp:.1f} s"
+        out["port_sample"] = f"CPU restatement, {threads} threads, {qw}x{qh}, {qspp} spp, {dtp:.1f} s"
     return out
 
 
