@@ -295,9 +295,9 @@ def test_fast_mode_against_the_references_own_ground_truth(gpu_ctx, name, w, h, 
         err = sigma * np.sqrt(1.0 / n_chunks + chunk / float(g["spp"]))
         got_mean, want_mean = float(np.mean(means)), float(mean.mean())
         assert abs(got_mean - want_mean) < max(1e-3 * want_mean, 4 * err), (accel, got_mean, want_mean, err)
-        # (rays per sample: 0.5 %; on the scene with the dense glass sphere the two arithmetics differ
-        # by 0.3 % in it, all of it in the paths that reach the depth cap, see below)
-        assert abs(rays / (w * h * chunk * n_chunks) / float(g["rays_per_sample"]) - 1) < 5e-3
+        # (rays per sample: 0.3 %; on the scene with the dense glass sphere the two arithmetics differ
+        # by 0.1 % in it, all of it in the paths that reach the depth cap, see below)
+        assert abs(rays / (w * h * chunk * n_chunks) / float(g["rays_per_sample"]) - 1) < 3e-3
         # path lengths
         ws, hs, ns = [int(v) for v in g["segments_hist_frame"]]
         gpu_ctx.upload(api.HostScene(name, ws, hs), accel)
@@ -311,9 +311,13 @@ def test_fast_mode_against_the_references_own_ground_truth(gpu_ctx, name, w, h, 
         # The last bin - paths cut off at the depth cap, Scene.cpp:108 - is kept apart: these are rays
         # caught inside a glass sphere by total internal reflection, which in exact arithmetic never
         # leave it; whether and when one escapes is decided by the rounding of each reflection, so
-        # the count depends on the arithmetic (measured on the scene with the ri 2.4 sphere: 11 650
-        # of 8.3 M paths in deterministic mode, 9 750 in fast mode, every other length agreeing
-        # within its noise).  They carry no radiance at the cap (Scene.cpp:108: `emitted`, which is 0).
+        # the count depends on the arithmetic.  With a fused discriminant in its sphere test the
+        # fast mode lost 16 % of these paths (and rendered glass spheres 1 - 2 % too bright: the
+        # rays that escape carry radiance, the ones cut off at the cap return `emitted`, 0,
+        # Scene.cpp:108); it now rounds the discriminant as the reference does (sphere_discriminant
+        # in rtx_core.h) and keeps 93 % of them (scene with the ri 2.4 sphere: 11 475 of 8.3 M
+        # paths in deterministic mode, 10 700 in fast mode, every other length agreeing within its
+        # noise; the radiance agrees cell by cell, see the test of the benchmark frames below).
         cap = 51
         keep = (ref_hist + fast_hist) >= 50
         keep[cap] = False
@@ -323,7 +327,7 @@ def test_fast_mode_against_the_references_own_ground_truth(gpu_ctx, name, w, h, 
         chi2 = float((((a - b) ** 2)[ok] / (a + b)[ok]).sum())
         dof = int(ok.sum()) - 1
         assert chi2 < dof + 5 * np.sqrt(2 * dof), (accel, chi2, dof)
-        assert abs(fast_hist[cap] - ref_hist[cap]) <= 0.3 * ref_hist[cap] + 5 * np.sqrt(ref_hist[cap] + 1), (
+        assert abs(fast_hist[cap] - ref_hist[cap]) <= 0.15 * ref_hist[cap] + 5 * np.sqrt(ref_hist[cap] + 1), (
             accel, fast_hist[cap], ref_hist[cap])
 
 
@@ -657,3 +661,48 @@ def test_full_size_frames_of_the_4k_and_the_100k_item_configurations(gpu_ctx):
     sample of the frame), its CPU frames through the restatement's own hierarchy."""
     _full_size_check(gpu_ctx, "cornell_extra", 3840, 2160, 3, True)
     _full_size_check(gpu_ctx, "bvh_stress", 1920, 1080, 3, False)
+
+
+@pytest.mark.parametrize("name,w,h,spp,accel", [("cornell", 1920, 1080, 1024, api.RTX_ACCEL_AUTO),
+                                                ("random_field", 1920, 1080, 256, api.RTX_ACCEL_AUTO),
+                                                ("bvh_stress", 1920, 1080, 128, api.RTX_ACCEL_AUTO),
+                                                ("cornell_extra", 3840, 2160, 64, api.RTX_ACCEL_AUTO)])
+def test_fast_mode_equals_deterministic_mode_at_the_benchmark_frames(gpu_ctx, name, w, h, spp, accel):
+    """The benchmark runs the fast mode at frame sizes no CPU oracle can render.  The deterministic
+    mode can (it is the reference bit for bit where the oracle reaches, and its sample ranges
+    compose), so at the benchmark's own frames - its tile sizes, pools and tree - the two modes are
+    compared as estimators: eight independent sample ranges each, the whole frame's radiance and
+    the radiance of every cell of a 16 x 9 grid (t-tests against the scatter between the ranges),
+    and the rays per sample.  A material or a subtree gone wrong in one part of the frame shows
+    up in its cells."""
+    k = 8
+    scene = api.HostScene(name, w, h)
+    gpu_ctx.upload(scene, accel)
+
+    def chunks(mode, seed):
+        frames, rays = [], 0
+        for c in range(k):
+            img, r = gpu_ctx.render(gpu_ctx.params(w, h, c * (spp // k), spp // k, mode=mode, seed=seed))
+            assert np.isfinite(img).all()
+            # 16 x 9 cells (both frame sizes divide)
+            frames.append(img.reshape(9, h // 9, 16, w // 16, 3).sum(axis=(1, 3, 4)).astype(np.float64))
+            rays += r
+        return np.stack(frames), rays
+
+    fast, rays_fast = chunks(api.RTX_MODE_FAST, 3)
+    det, rays_det = chunks(api.RTX_MODE_DETERMINISTIC, 4)
+    # paths cut off at the depth cap (rays caught in the glass spheres) are a few per mille of the
+    # segments and their number depends on rounding: see the ground-truth test
+    assert abs(rays_fast / rays_det - 1) < (3e-3 if name == "cornell_extra" else 2e-3), rays_fast / rays_det
+    # whole frame
+    tf, td = fast.sum(axis=(1, 2)), det.sum(axis=(1, 2))
+    se = np.sqrt(tf.var(ddof=1) / k + td.var(ddof=1) / k)
+    assert abs(tf.mean() - td.mean()) < 4.5 * se + 2e-4 * td.mean(), (tf.mean() / td.mean(), se / td.mean())
+    # cell by cell
+    se_cell = np.sqrt(fast.var(axis=0, ddof=1) / k + det.var(axis=0, ddof=1) / k)
+    lit = det.mean(axis=0) > 1e-6 * det.mean(axis=0).max()  # (cells that see nothing at all: 0 = 0)
+    z = (fast.mean(axis=0) - det.mean(axis=0))[lit] / np.maximum(se_cell[lit], 1e-30)
+    # z follows a t distribution with about 14 degrees of freedom: rms 1.08, 144 cells rarely beyond 5
+    assert 0.6 < np.sqrt(np.mean(z ** 2)) < 1.6, np.sqrt(np.mean(z ** 2))
+    assert np.abs(z).max() < 6.5, np.abs(z).max()
+    assert abs(np.mean(z)) < 0.45, np.mean(z)  # no common drift (standard error of the mean of 144 z: 0.09)
