@@ -39,3 +39,5 @@ print(f"{name} {w}x{h}x{spp} accel {ctx.info().accel}: rms z {np.sqrt(np.mean(z[
 if "--map" in sys.argv:
     np.set_printoptions(linewidth=200, precision=1, suppress=True)
     print(z)
+    print("fast / det - 1, in 1e-4:")
+    print(np.where(lit, (a.mean(axis=0) / np.maximum(b.mean(axis=0), 1e-30) - 1) * 1e4, 0.0))
