@@ -663,18 +663,10 @@ def test_full_size_frames_of_the_4k_and_the_100k_item_configurations(gpu_ctx):
     _full_size_check(gpu_ctx, "bvh_stress", 1920, 1080, 3, False)
 
 
-@pytest.mark.parametrize("name,w,h,spp,accel", [("cornell", 1920, 1080, 1024, api.RTX_ACCEL_AUTO),
-                                                ("random_field", 1920, 1080, 256, api.RTX_ACCEL_AUTO),
-                                                ("bvh_stress", 1920, 1080, 128, api.RTX_ACCEL_AUTO),
-                                                ("cornell_extra", 3840, 2160, 64, api.RTX_ACCEL_AUTO)])
-def test_fast_mode_equals_deterministic_mode_at_the_benchmark_frames(gpu_ctx, name, w, h, spp, accel):
-    """The benchmark runs the fast mode at frame sizes no CPU oracle can render.  The deterministic
-    mode can (it is the reference bit for bit where the oracle reaches, and its sample ranges
-    compose), so at the benchmark's own frames - its tile sizes, pools and tree - the two modes are
-    compared as estimators: eight independent sample ranges each, the whole frame's radiance and
-    the radiance of every cell of a 16 x 9 grid (t-tests against the scatter between the ranges),
-    and the rays per sample.  A material or a subtree gone wrong in one part of the frame shows
-    up in its cells."""
+def _fast_against_deterministic_cell_by_cell(gpu_ctx, name, w, h, spp, accel, rays_tol):
+    """Fast and deterministic mode as estimators of one picture: eight independent sample ranges
+    each, the whole frame's radiance and the radiance of every cell of a 16 x 9 grid (t-tests against
+    the scatter between the ranges), and the rays per sample."""
     k = 8
     scene = api.HostScene(name, w, h)
     gpu_ctx.upload(scene, accel)
@@ -684,16 +676,14 @@ def test_fast_mode_equals_deterministic_mode_at_the_benchmark_frames(gpu_ctx, na
         for c in range(k):
             img, r = gpu_ctx.render(gpu_ctx.params(w, h, c * (spp // k), spp // k, mode=mode, seed=seed))
             assert np.isfinite(img).all()
-            # 16 x 9 cells (both frame sizes divide)
+            # 16 x 9 cells (the frame sizes used divide)
             frames.append(img.reshape(9, h // 9, 16, w // 16, 3).sum(axis=(1, 3, 4)).astype(np.float64))
             rays += r
         return np.stack(frames), rays
 
     fast, rays_fast = chunks(api.RTX_MODE_FAST, 3)
     det, rays_det = chunks(api.RTX_MODE_DETERMINISTIC, 4)
-    # paths cut off at the depth cap (rays caught in the glass spheres) are a few per mille of the
-    # segments and their number depends on rounding: see the ground-truth test
-    assert abs(rays_fast / rays_det - 1) < (3e-3 if name == "cornell_extra" else 2e-3), rays_fast / rays_det
+    assert abs(rays_fast / rays_det - 1) < rays_tol, rays_fast / rays_det
     # whole frame
     tf, td = fast.sum(axis=(1, 2)), det.sum(axis=(1, 2))
     se = np.sqrt(tf.var(ddof=1) / k + td.var(ddof=1) / k)
@@ -703,6 +693,38 @@ def test_fast_mode_equals_deterministic_mode_at_the_benchmark_frames(gpu_ctx, na
     lit = det.mean(axis=0) > 1e-6 * det.mean(axis=0).max()  # (cells that see nothing at all: 0 = 0)
     z = (fast.mean(axis=0) - det.mean(axis=0))[lit] / np.maximum(se_cell[lit], 1e-30)
     # z follows a t distribution with about 14 degrees of freedom: rms 1.08, 144 cells rarely beyond 5
+    # (two runs of ONE mode against each other give an rms of 1.07 - 1.19)
     assert 0.6 < np.sqrt(np.mean(z ** 2)) < 1.6, np.sqrt(np.mean(z ** 2))
     assert np.abs(z).max() < 6.5, np.abs(z).max()
     assert abs(np.mean(z)) < 0.45, np.mean(z)  # no common drift (standard error of the mean of 144 z: 0.09)
+
+
+@pytest.mark.parametrize("name,w,h,spp,accel", [("cornell", 1920, 1080, 1024, api.RTX_ACCEL_AUTO),
+                                                ("random_field", 1920, 1080, 256, api.RTX_ACCEL_AUTO),
+                                                ("bvh_stress", 1920, 1080, 128, api.RTX_ACCEL_AUTO),
+                                                ("cornell_extra", 3840, 2160, 64, api.RTX_ACCEL_AUTO)])
+def test_fast_mode_equals_deterministic_mode_at_the_benchmark_frames(gpu_ctx, name, w, h, spp, accel):
+    """The benchmark runs the fast mode at frame sizes no CPU oracle can render.  The deterministic
+    mode can (it is the reference bit for bit where the oracle reaches, and its sample ranges
+    compose), so at the benchmark's own frames - its tile sizes, pools and tree - the two modes are
+    compared as estimators, cell by cell.  A material or a subtree gone wrong in one part of the
+    frame shows up in its cells: this test found the fused discriminant of the sphere test
+    (sphere_discriminant in rtx_core.h), which made glass spheres 1 - 2 % too bright."""
+    # paths cut off at the depth cap (rays caught in the glass spheres) are a few per mille of the
+    # segments and their number depends on rounding: see the ground-truth test
+    _fast_against_deterministic_cell_by_cell(gpu_ctx, name, w, h, spp, accel, 3e-3 if name == "cornell_extra" else 2e-3)
+
+
+@pytest.mark.parametrize("name,accel", [("small", api.RTX_ACCEL_LINEAR), ("cornell_classic", api.RTX_ACCEL_LINEAR),
+                                        ("textured", api.RTX_ACCEL_LINEAR), ("textured", api.RTX_ACCEL_BVH),
+                                        ("sky_spheres", api.RTX_ACCEL_LINEAR), ("sky_sphere_lit", api.RTX_ACCEL_LINEAR),
+                                        ("cornell_light_tree", api.RTX_ACCEL_LINEAR),
+                                        ("cornell_side_lights", api.RTX_ACCEL_LINEAR),
+                                        ("cornell_many_lights", api.RTX_ACCEL_LINEAR),
+                                        ("cornell_many_lights_10", api.RTX_ACCEL_BVH),
+                                        ("random_field", api.RTX_ACCEL_LINEAR), ("bvh_stress_2000", api.RTX_ACCEL_BVH),
+                                        ("cornell_extra", api.RTX_ACCEL_BVH)])
+def test_fast_mode_equals_deterministic_mode_cell_by_cell_on_every_scene(gpu_ctx, name, accel):
+    """The same comparison at 960x540 x 512 spp over the other named scenes, scan and tree: textures,
+    the sky, nested / general / many lights."""
+    _fast_against_deterministic_cell_by_cell(gpu_ctx, name, 960, 540, 512, accel, 3e-3)
