@@ -254,6 +254,13 @@ rtxd::ScanHit make_scan_hit(const rtxd::Prim& P, const rtxd::PrimInfo& I, const 
     rtxd::ScanHit H{};
     H.r = I.r; H.g = I.g; H.b = I.b; H.param = I.param;
     H.bits = I.bits; H.texture = I.texture;
+    if (((I.bits >> rtxd::kInfoMatShift) & 3u) == RTX_MAT_DIELECTRIC) {
+        // a Dielectric has no colour (its weight is 1, Dielectric.cpp:22): the slots carry what its
+        // scattering code would otherwise work out per hit, 1 / ri and Schlick's r0 (Util.h:73-76)
+        const double ri = I.param, q = (1.0 - ri) / (1.0 + ri);
+        H.r = (float)(1.0 / ri);
+        H.g = (float)(q * q);
+    }
     H.group = g;
     H.chained = S.identity ? 0u : 1u;
     // group -> world: p_world = M^T (p_local - m)

@@ -1378,7 +1378,8 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
             const float ri = rec.param;
             const bool inside = dn > 0.0f;
             const V3 outward = inside ? -rec.n : rec.n;
-            const float ni_over_nt = inside ? ri : frcp(ri);
+            // (the hit table holds 1 / ri and Schlick's r0 in the colour slots of a Dielectric)
+            const float ni_over_nt = inside ? ri : rec.color.x;
             const float dt = __builtin_fabsf(dn) * inv_len;          // dot(normalize(-d), outward)
             const float cosine = inside ? ri * dt : dt;               // Dielectric.cpp:19,24
             const float D = 1.0f - (ni_over_nt * ni_over_nt) * (1.0f - dt * dt);  // refract, Util.h:60-71
@@ -1387,7 +1388,8 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
             if (D > 0.0f) {
                 const V3 uv = ps.d * (-inv_len);
                 refracted = (uv - outward * dt) * (-ni_over_nt) - outward * fsqrt(D);
-                reflect_prob = schlick(cosine, ri);
+                const float m = 1.0f - cosine, m2 = m * m, r0 = rec.color.y;
+                reflect_prob = r0 + (1.0f - r0) * ((m2 * m2) * m);  // schlick, Util.h:73-76
             }
             if (!(rng_nextf(&ps.rng) < reflect_prob)) dir = refracted;
             // albedo is (1,1,1): the weight is unchanged
