@@ -966,7 +966,10 @@ RTX_DEV float cone_cosine(float rr, float dd) {
 #if RTX_DET
     return fsqrt(1.0f - rr * frcp(dd));
 #else
-    return fsqrt(__builtin_fmaxf(1.0f - rr * frcp(dd), 0.0f));
+    // sqrt((dd - rr) / dd) with one reciprocal square root: x * rsqrt(x * dd); x = 0 (inside the
+    // sphere) gives 0, not NaN, through the floor under the product
+    const float x = __builtin_fmaxf(dd - rr, 0.0f);
+    return x * finvsqrt(__builtin_fmaxf(x * dd, 1.0e-30f));
 #endif
 }
 
