@@ -208,7 +208,9 @@ def test_fast_bvh_kernel_follows_the_paths_of_the_fast_scan(gpu_ctx, monkeypatch
         assert bvh_rays == lin_rays
     elif same.size >= 4096:
         assert abs(float(bvh_rgb.sum()) / float(lin_rgb.sum()) - 1) < 2e-2
-        assert abs(bvh_rays / lin_rays - 1) < 2e-3
+        # (a path that orbits inside a glass sphere in one kernel and leaves it in the other differs by
+        # up to 50 segments: four such paths are allowed on top of the 0.2 %)
+        assert abs(bvh_rays / lin_rays - 1) < 2e-3 + 4 * 51 / lin_rays
     # the frame the kernel accumulates is the sum of the samples it reports
     flipped = bvh_rgb.reshape(h, w, spp, 3).sum(axis=2)[::-1]
     assert np.allclose(bvh_sum, flipped, rtol=1e-4, atol=1e-5)
