@@ -369,13 +369,13 @@ void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rt
 // instructions of a step down the two-child tree, so it pays when it saves enough steps: by the
 // surface-area estimates of the builder (expected node visits of a ray through the root box), the
 // wide tree is used when the two-child tree needs at least kWideMinVisitRatio times its visits.
-// Measured at 1080p, wide against two-child, Grays/s (ratio of the estimates): 487-sphere field 21.0 /
-// 21.7 (2.52); 200 / 500 / 1 000 / 2 000 / 20 000 / 100 000 items in a slab 45.7 / 45.6 (2.65), 37.4 / 35.5
-// (2.74), 29.9 / 28.8 (2.83), 25.0 / 23.3 (2.86), 11.6 / 10.6 (2.99), 6.42 / 5.93 (3.04); a 12-item Cornell
-// box 19.4 / 17.7 (4.30), one with 104 lights 9.6 / 8.6 (4.45).
+// Measured at 1080p, wide against two-child, Grays/s (ratio of the estimates): 487-sphere field 21.7 /
+// 23.7 (2.52); 200 / 500 / 1 000 / 2 000 / 20 000 items in a slab 46.0 / 46.9 (2.65), 37.6 / 35.9 (2.74),
+// 30.0 / 29.7 (2.83), 25.1 / 23.6 (2.86), 11.6 / 10.5 (2.99); 100 000 items 6.42 / 5.93 (3.04); a 12-item
+// Cornell box 19.4 / 17.7 (4.30), one with 104 lights 9.6 / 8.6 (4.45).
 // RTX_WIDE_MIN_RATIO and RTX_WIDE_MIN_ITEMS (scenes with fewer tree items walk the two-child tree)
 // override, for measurements and tests; RTX_TREE_STATS prints the estimates.
-constexpr double kWideMinVisitRatio = 2.6;
+constexpr double kWideMinVisitRatio = 2.7;
 double wide_min_ratio() {
     const char* e = std::getenv("RTX_WIDE_MIN_RATIO");  // read at every upload: tests switch it
     return e ? std::atof(e) : kWideMinVisitRatio;

@@ -1752,7 +1752,14 @@ RTX_DEV uint32_t wide_node_hits(uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint4 n4
 #ifndef RTX_WALK_STEPS
 #define RTX_WALK_STEPS 4    // traversal steps between two looks at the wave's state (1 .. 16 measured)
 #endif
-constexpr uint32_t kShadeBatch = RTX_SHADE_BATCH;
+// ... and for the two-child tree, whose steps are a third as long (487-sphere field: 4 / 8 / 16 walk
+// steps 22.5 / 23.5 / 23.2 Grays/s, shade batch 16 / 24 / 32 20.8 / 22.5 / 23.1)
+#ifndef RTX_SHADE_BATCH2
+#define RTX_SHADE_BATCH2 32
+#endif
+#ifndef RTX_WALK_STEPS2
+#define RTX_WALK_STEPS2 8
+#endif
 #ifndef RTX_LEAF_BATCH
 #define RTX_LEAF_BATCH 8  // measured 4 .. 32
 #endif
@@ -1849,6 +1856,7 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
         const unsigned long long idle = __ballot(phase == kIdle);
         const bool pool_left = next < total;
         const uint32_t waiting = n_done + (pool_left ? (uint32_t)__popcll(idle) : 0u);
+        constexpr uint32_t kShadeBatch = kWide ? RTX_SHADE_BATCH : RTX_SHADE_BATCH2;
         if (waiting != 0u && (walking == 0ull || waiting >= kShadeBatch)) {
             RTX_STAT(5, 1u);      // [5] shade / refill passes of the wave
             RTX_STAT(6, n_done);  // [6] ... lanes shaded
@@ -1939,7 +1947,7 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
             continue;                  // this draw fell outside the image (ragged tile): draw again
         }
 #pragma unroll 1
-        for (int step = 0; step < RTX_WALK_STEPS; ++step) {
+        for (int step = 0; step < (kWide ? RTX_WALK_STEPS : RTX_WALK_STEPS2); ++step) {
             RTX_STAT(4, 1u);  // [4] walk steps of the wave
             // A lane with items left tests one; a lane without takes the next inner child of its
             // node group one node down.  Lanes with items hold them until kLeafBatch of them have
