@@ -331,6 +331,9 @@ void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rt
         rtxd::ScanGroup S{};
         compose_chain(steps, G.step_begin, G.step_end, S.m);
         S.identity = G.step_end == G.step_begin ? 1u : 0u;
+        // Rotate about (0,1,0) - what the reference's own scene uses (Scene.cpp:75-77) - composes to a
+        // matrix whose y row and column are those of the identity, exactly
+        S.rot_y = (!S.identity && S.m[1] == 0.0f && S.m[3] == 0.0f && S.m[5] == 0.0f && S.m[7] == 0.0f && S.m[4] == 1.0f) ? 1u : 0u;
         S.first = (uint32_t)sr.size();
         const auto boxes = find_boxes(prims, G.prim_begin, G.prim_end, used);
         uint32_t* counts[4] = {&S.n_xy, &S.n_xz, &S.n_yz, &S.n_sph};

@@ -542,7 +542,13 @@ RTX_DEV void scan_boxes(const SceneView& sc, uint32_t& pos, uint32_t count, V3 r
         const float t = tn >= t0 ? tn : tf;
         const bool ok = (tn <= tf) & (t >= t0) & (t <= closest);
         // the face is the plane whose distance t is (slot order +z -z +y -y +x -x)
-        const uint32_t face = t == lx ? 5u : (t == hx ? 4u : (t == ly ? 3u : (t == hy ? 2u : (t == lz ? 1u : 0u))));
+        // (one select per plane: as a chain of nested conditionals it became four nested branches)
+        uint32_t face = 0u;
+        face = t == lz ? 1u : face;
+        face = t == hy ? 2u : face;
+        face = t == ly ? 3u : face;
+        face = t == hx ? 4u : face;
+        face = t == lx ? 5u : face;
         closest = ok ? t : closest;
         best = ok ? pos + face : best;
     }
@@ -554,7 +560,10 @@ RTX_DEV bool query_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, f
     for (uint32_t g = 0; g < sc.n_scan_groups; ++g) {
         const ScanGroup G = load_uniform(sc.scan_groups, g);
         V3 ro = o, rd = d;
-        if (!G.identity) {
+        if (G.rot_y) {  // the products with the exact zeros and the one of the map left out
+            ro = v3(G.m[0] * o.x + G.m[2] * o.z + G.m[9], o.y + G.m[10], G.m[6] * o.x + G.m[8] * o.z + G.m[11]);
+            rd = v3(G.m[0] * d.x + G.m[2] * d.z, d.y, G.m[6] * d.x + G.m[8] * d.z);
+        } else if (!G.identity) {
             ro = v3(G.m[0] * o.x + G.m[1] * o.y + G.m[2] * o.z + G.m[9],
                     G.m[3] * o.x + G.m[4] * o.y + G.m[5] * o.z + G.m[10],
                     G.m[6] * o.x + G.m[7] * o.y + G.m[8] * o.z + G.m[11]);

@@ -55,7 +55,8 @@ struct alignas(16) ScanGroup {
     uint32_t n_xy, n_xz, n_yz, n_sph;
     uint32_t identity;     // 1: no transform
     uint32_t n_box;
-    uint32_t pad;
+    uint32_t rot_y;        // 1: the map is a rotation about the y axis and a translation (m[1] = m[3] =
+                           // m[5] = m[7] = 0 and m[4] = 1 exactly): the terms that vanish are not computed
 };
 constexpr uint32_t kBoxSlots = 6;
 
