@@ -369,6 +369,9 @@ def main() -> int:
     frame_accum = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)  # rank 0: running frame
     rays = torch.zeros(1, dtype=torch.int64, device=dev)
     if engine is None:
+        # the 8-bit image of every step lands in page-locked memory: the copy back is then a DMA transfer
+        # and not a series of copy kernels that share the CUs with the next step's rendering
+        image_host = torch.empty((h, w, 3), dtype=torch.uint8).pin_memory().numpy() if rank == 0 else None
         render_stream = torch.cuda.current_stream(dev)
         # reduce + resolve of step k while step k+1 renders
         side_stream = render_stream if args.serial else torch.cuda.Stream(dev)
@@ -406,7 +409,8 @@ def main() -> int:
             frame_accum.add_(buf)
             if engine is not None:
                 return api.resolve_host(frame_accum.numpy(), total_spp_done)
-            return ctx.resolve_device(w, h, total_spp_done, frame_accum.data_ptr(), side_stream.cuda_stream)
+            return ctx.resolve_device(w, h, total_spp_done, frame_accum.data_ptr(), side_stream.cuda_stream,
+                                      out=image_host)
         return None
 
     run_pipelined_steps(range(args.warmup), render, combine, step_accum, render_stream, side_stream)

@@ -356,8 +356,14 @@ class Context:
                                       hits.ctypes.data))
         return hits
 
-    def resolve_device(self, width: int, height: int, ns: int, d_accum: int, stream: int = 0) -> np.ndarray:
-        out = np.zeros((height, width, 3), np.uint8)
+    def resolve_device(self, width: int, height: int, ns: int, d_accum: int, stream: int = 0,
+                       out: Optional[np.ndarray] = None) -> np.ndarray:
+        """rtx_resolve_device into `out` (a C-contiguous uint8 [height, width, 3] array; give one that
+        lives in page-locked memory and the copy back runs on a DMA engine instead of through a staging
+        buffer filled by copy kernels) or into a new array."""
+        if out is None:
+            out = np.zeros((height, width, 3), np.uint8)
+        assert out.dtype == np.uint8 and out.flags.c_contiguous and out.shape == (height, width, 3)
         self._check(self._lib.rtx_resolve_device(self._ctx, width, height, ns, C.c_void_p(d_accum),
                                                  out.ctypes.data, C.c_void_p(stream) if stream else None))
         return out

@@ -722,8 +722,8 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
             return fail(RTX_ERR_TOO_LARGE, "BVH is deeper than the traversal stack");
         build_bvh_fast_items(prims, info, items, steps, fast_items, fast_maps, scan_info, scan_orig);
         if (std::getenv("RTX_TREE_STATS"))
-            std::fprintf(stderr, "rtx tree: %zu items, %zu two-child nodes (%.2f visits), %zu wide nodes (%.2f visits), ratio %.2f\n",
-                         items.size(), tree.nodes.size(), tree.visits_two_child, tree.wide.size(), tree.visits_wide,
+            std::fprintf(stderr, "rtx tree: %zu items, %zu two-child nodes (depth %d, %.2f visits), %zu wide nodes (%.2f visits), ratio %.2f\n",
+                         items.size(), tree.nodes.size(), tree.depth, tree.visits_two_child, tree.wide.size(), tree.visits_wide,
                          tree.visits_wide > 0.0 ? tree.visits_two_child / tree.visits_wide : 0.0);
         // the eight-wide tree of the fast trace kernel reads the leaf records in its own order; a
         // tree deeper than that kernel's stack, or one that saves too few steps (see
