@@ -130,12 +130,12 @@ Grid make_grid(const Box& root) {
 // Outward rounding by one whole step beyond floor / ceil: the traversal evaluates
 // origin + q * scale folded into the ray's slab constants in fp32, whose rounding error is
 // orders of magnitude below a grid step (1 / 65530 of the scene's extent).
-void store_box(uint16_t lo[3], uint16_t hi[3], const Box& b, const Grid& g) {
+void store_box(uint16_t q[3][2], const Box& b, const Grid& g) {
     for (int a = 0; a < 3; ++a) {
         const double l = std::floor((b.lo[a] - (double)g.origin[a]) / (double)g.scale[a]) - 1.0;
         const double h = std::ceil((b.hi[a] - (double)g.origin[a]) / (double)g.scale[a]) + 1.0;
-        lo[a] = (uint16_t)std::min(std::max(l, 0.0), 65535.0);
-        hi[a] = (uint16_t)std::min(std::max(h, 0.0), 65535.0);
+        q[a][0] = (uint16_t)std::min(std::max(l, 0.0), 65535.0);
+        q[a][1] = (uint16_t)std::min(std::max(h, 0.0), 65535.0);
     }
 }
 
@@ -517,8 +517,8 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
         // (the leaf is then visited twice when the ray meets its box: harmless, a primitive
         // that already holds the nearest hit does not win against itself)
         rtxd::BvhNode R{};
-        store_box(R.lo0, R.hi0, nodes[0].box, grid);
-        store_box(R.lo1, R.hi1, nodes[0].box, grid);
+        store_box(R.box0, nodes[0].box, grid);
+        store_box(R.box1, nodes[0].box, grid);
         R.child0 = ref_of(0);
         R.child1 = R.child0;
         out_nodes.push_back(R);
@@ -530,8 +530,8 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
         if (N.count != 0) continue;
         rtxd::BvhNode& O = out_nodes[inner_index[k]];
         O = rtxd::BvhNode{};
-        store_box(O.lo0, O.hi0, nodes[N.left].box, grid);
-        store_box(O.lo1, O.hi1, nodes[N.left + 1].box, grid);
+        store_box(O.box0, nodes[N.left].box, grid);
+        store_box(O.box1, nodes[N.left + 1].box, grid);
         O.child0 = ref_of(N.left);
         O.child1 = ref_of(N.left + 1);
     }

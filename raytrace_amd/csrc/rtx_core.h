@@ -645,11 +645,11 @@ RTX_DEV BvhRay bvh_ray(const SceneView& sc, V3 inv, V3 noi) {
              __builtin_fmaf(sc.bvh_origin[2], inv.z, noi.z));
     return r;
 }
-// One child's box: w0 = lo.x | lo.y << 16, w1 = lo.z | hi.x << 16, w2 = hi.y | hi.z << 16.
+// One child's box: w0 = lo.x | hi.x << 16, w1 = lo.y | hi.y << 16, w2 = lo.z | hi.z << 16.
 // Conservative; returns the entry distance.
 RTX_DEV bool slab(uint32_t w0, uint32_t w1, uint32_t w2, const BvhRay& r, float t0, float t1, float& t_near) {
-    const float lx = (float)(w0 & 0xffffu), ly = (float)(w0 >> 16), lz = (float)(w1 & 0xffffu);
-    const float hx = (float)(w1 >> 16), hy = (float)(w2 & 0xffffu), hz = (float)(w2 >> 16);
+    const float lx = (float)(w0 & 0xffffu), ly = (float)(w1 & 0xffffu), lz = (float)(w2 & 0xffffu);
+    const float hx = (float)(w0 >> 16), hy = (float)(w1 >> 16), hz = (float)(w2 >> 16);
     float tx0 = __builtin_fmaf(lx, r.A.x, r.B.x), tx1 = __builtin_fmaf(hx, r.A.x, r.B.x);
     float ty0 = __builtin_fmaf(ly, r.A.y, r.B.y), ty1 = __builtin_fmaf(hy, r.A.y, r.B.y);
     float tz0 = __builtin_fmaf(lz, r.A.z, r.B.z), tz1 = __builtin_fmaf(hz, r.A.z, r.B.z);
@@ -658,6 +658,33 @@ RTX_DEV bool slab(uint32_t w0, uint32_t w1, uint32_t w2, const BvhRay& r, float 
     t_near = tn;
     return tn <= tf;
 }
+#if !RTX_DET
+// The same test when the ray knows which plane of each axis it meets first.  The five low mantissa
+// bits of B hold 16 where the ray runs towards -axis and 0 where it runs towards +axis
+// (bvh_ray_signed; 31 ulp of B move a plane by a few millionths of the distance between the ray's
+// origin and the grid's, a hundredth of the padding of the boxes): a rotate of the word by that
+// amount - v_alignbit_b32 reads the amount from just those bits - leaves near | far << 16, and the
+// three min / max pairs of the plain test are gone.
+RTX_DEV BvhRay bvh_ray_signed(const SceneView& sc, V3 inv, V3 noi) {
+    BvhRay r = bvh_ray(sc, inv, noi);
+    r.B.x = __uint_as_float((__float_as_uint(r.B.x) & ~31u) | ((__float_as_uint(r.A.x) >> 27) & 16u));
+    r.B.y = __uint_as_float((__float_as_uint(r.B.y) & ~31u) | ((__float_as_uint(r.A.y) >> 27) & 16u));
+    r.B.z = __uint_as_float((__float_as_uint(r.B.z) & ~31u) | ((__float_as_uint(r.A.z) >> 27) & 16u));
+    return r;
+}
+RTX_DEV bool slab_signed(uint32_t w0, uint32_t w1, uint32_t w2, const BvhRay& r, float t0, float t1, float& t_near) {
+    const uint32_t x = __builtin_amdgcn_alignbit(w0, w0, __float_as_uint(r.B.x));
+    const uint32_t y = __builtin_amdgcn_alignbit(w1, w1, __float_as_uint(r.B.y));
+    const uint32_t z = __builtin_amdgcn_alignbit(w2, w2, __float_as_uint(r.B.z));
+    const float nx = __builtin_fmaf((float)(x & 0xffffu), r.A.x, r.B.x), fx = __builtin_fmaf((float)(x >> 16), r.A.x, r.B.x);
+    const float ny = __builtin_fmaf((float)(y & 0xffffu), r.A.y, r.B.y), fy = __builtin_fmaf((float)(y >> 16), r.A.y, r.B.y);
+    const float nz = __builtin_fmaf((float)(z & 0xffffu), r.A.z, r.B.z), fz = __builtin_fmaf((float)(z >> 16), r.A.z, r.B.z);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx, ny), nz), t0);
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(fx, fy), fz), t1);
+    t_near = tn;
+    return tn <= tf;
+}
+#endif
 // A node as its eight 32-bit words (two 16-byte loads).
 struct NodeWords {
     uint4 a, b;  // a.xyz: child 0's box, a.w | b.xy: child 1's box, b.z / b.w: the children
@@ -1938,7 +1965,7 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     ng_bits = 0x80000000u;
                     ig_bits = 0u;
                 } else {
-                    br = bvh_ray(sc, inv, noi);
+                    br = bvh_ray_signed(sc, inv, noi);
                     ref = 0u;  // root
                 }
                 sp = 0u;
@@ -2011,8 +2038,8 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 if (at_node) {
                     const NodeWords N = load_node(sc, ref);
                     float n0, n1;
-                    const bool h0 = slab(N.a.x, N.a.y, N.a.z, br, kTMin, closest, n0);
-                    const bool h1 = slab(N.a.w, N.b.x, N.b.y, br, kTMin, closest, n1);
+                    const bool h0 = slab_signed(N.a.x, N.a.y, N.a.z, br, kTMin, closest, n0);
+                    const bool h1 = slab_signed(N.a.w, N.b.x, N.b.y, br, kTMin, closest, n1);
                     if (h0 & h1) {  // the nearer child first, the other waits on the stack
                         const bool first0 = n0 <= n1;
                         if (sp < (uint32_t)kBvhStack) s_stack2[sp][tid] = first0 ? N.b.w : N.b.z;

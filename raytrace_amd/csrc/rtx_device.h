@@ -148,9 +148,12 @@ constexpr uint32_t kLightsTree = 2u;     // nested lists, chains or XY / YZ rect
 // (world = bvh_origin + q * bvh_scale per axis, rounded outwards when built), decoded inside the
 // slab test's fused multiply-adds.  A child reference is either the index of another node or,
 // with kBvhLeaf set, a leaf: items [ref & kBvhLeafFirst, + ((ref >> 27) & 15)] of `bvh_items`.
+// Per child and axis the two planes share one 32-bit word (lo | hi << 16): the fast trace kernel
+// turns it into (near | far << 16) for its ray with one rotate by 0 or 16 bits instead of a min and
+// a max per axis.
 struct alignas(32) BvhNode {
-    uint16_t lo0[3], hi0[3];
-    uint16_t lo1[3], hi1[3];
+    uint16_t box0[3][2];  // [axis][0 = lo, 1 = hi]
+    uint16_t box1[3][2];
     uint32_t child0, child1;
 };
 // Entries of the traversal's per-lane stack: one deferred child per level, so a tree may be at

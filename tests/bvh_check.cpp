@@ -219,9 +219,13 @@ int main(int argc, char** argv) {
             }
             const rtxd::BvhNode& N = tree.nodes[ref];
             double lo[3], hi[3];
-            decode(N.lo0, lo); decode(N.hi0, hi);
+            const auto planes = [](const uint16_t q[3][2], int k, uint16_t out[3]) { for (int a = 0; a < 3; ++a) out[a] = q[a][k]; };
+            uint16_t ql[3], qh[3];
+            planes(N.box0, 0, ql); planes(N.box0, 1, qh);
+            decode(ql, lo); decode(qh, hi);
             if (ray_box(o, d, lo, hi)) todo.push_back(N.child0);
-            decode(N.lo1, lo); decode(N.hi1, hi);
+            planes(N.box1, 0, ql); planes(N.box1, 1, qh);
+            decode(ql, lo); decode(qh, hi);
             if (ray_box(o, d, lo, hi)) todo.push_back(N.child1);
         }
         for (uint32_t k = 0; k < n_tree_items; ++k) {
