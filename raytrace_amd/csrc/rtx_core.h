@@ -1713,27 +1713,29 @@ RTX_DEV float ubyte(uint32_t w) { return (float)((w >> (8 * K)) & 0xffu); }
 // child's box on the node's grid is p + q * 2^e; along the ray that is
 // t(q) = q * (2^e * inv) + (p * inv + noi), one conversion and one fma per plane.  Which of the
 // two planes of an axis the ray meets first depends only on the sign of its direction, so the
-// caller hands over the near and far bytes already selected: no min / max per axis.
+// caller hands over the near and far bytes already selected: no min / max per axis.  The
+// outcome is shifted into `hits` from below (compare into vcc, add with carry: one full-rate
+// instruction instead of a select, a shift and an or per child).
 template <int K>
 RTX_DEV uint32_t wide_child(uint32_t xn, uint32_t yn, uint32_t zn, uint32_t xf, uint32_t yf, uint32_t zf, V3 s, V3 b,
-                            float t0, float closest, uint32_t meta4, uint32_t index4, uint32_t hitmask) {
+                            float t0, float closest, uint32_t hits) {
     const float tnx = __builtin_fmaf(ubyte<K>(xn), s.x, b.x), tny = __builtin_fmaf(ubyte<K>(yn), s.y, b.y),
                 tnz = __builtin_fmaf(ubyte<K>(zn), s.z, b.z);
     const float tfx = __builtin_fmaf(ubyte<K>(xf), s.x, b.x), tfy = __builtin_fmaf(ubyte<K>(yf), s.y, b.y),
                 tfz = __builtin_fmaf(ubyte<K>(zf), s.z, b.z);
     const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz), t0);
     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(tfx, tfy), tfz), closest);
-    // the slot's bits (1 for an inner node, its items in unary for a leaf, 0 for an empty slot)
-    // at the slot's place in the hit mask
-    const uint32_t bits = (meta4 >> (8 * K + 5)) & 7u, index = (index4 >> (8 * K)) & 31u;
-    return tn <= tf ? hitmask | (bits << index) : hitmask;
+    asm("v_cmp_le_f32 vcc, %1, %2\n\t"
+        "v_addc_co_u32 %0, vcc, %0, %0, vcc"
+        : "+v"(hits)
+        : "v"(tn), "v"(tf)
+        : "vcc");
+    return hits;
 }
 
-// The hit mask of one node: bits 24-31 the inner children the ray meets, placed in the order
-// the ray wants to visit them (highest bit first), bits 0-23 the items of the leaves it meets
-// (relative to the node's item_base).
-RTX_DEV uint32_t wide_node_hits(uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint4 n4, V3 inv, V3 noi, uint32_t oct_inv4,
-                                float t0, float closest) {
+// The slots of one node whose box the ray meets (bit s = slot s; an empty slot holds an
+// inverted box that no ray meets).
+RTX_DEV uint32_t wide_node_hits(uint4 n0, uint4 n2, uint4 n3, uint4 n4, V3 inv, V3 noi, float t0, float closest) {
     V3 s, b;
     s.x = __uint_as_float((n0.w & 0xffu) << 23) * inv.x;
     s.y = __uint_as_float((n0.w & 0xff00u) << 15) * inv.y;
@@ -1744,32 +1746,39 @@ RTX_DEV uint32_t wide_node_hits(uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint4 n4
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     // words: n2 = qlo.x[0-3] qlo.x[4-7] qlo.y[0-3] qlo.y[4-7]; n3 = qlo.z.. qlo.z.. qhi.x.. qhi.x..;
     //        n4 = qhi.y.. qhi.y.. qhi.z.. qhi.z..
-    uint32_t hitmask = 0u;
-    {
-        const uint32_t xn = nx ? n3.z : n2.x, xf = nx ? n2.x : n3.z;
-        const uint32_t yn = ny ? n4.x : n2.z, yf = ny ? n2.z : n4.x;
-        const uint32_t zn = nz ? n4.z : n3.x, zf = nz ? n3.x : n4.z;
-        const uint32_t meta4 = n1.z;
-        const uint32_t inner4 = ((meta4 & (meta4 << 1)) & 0x10101010u) << 3;  // 0x80 in the bytes of inner slots
-        const uint32_t index4 = meta4 ^ (oct_inv4 & ((inner4 - (inner4 >> 7)) | inner4));
-        hitmask = wide_child<0>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
-        hitmask = wide_child<1>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
-        hitmask = wide_child<2>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
-        hitmask = wide_child<3>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
-    }
+    uint32_t hits = 0u;  // slot 7 first: it ends up in bit 7
     {
         const uint32_t xn = nx ? n3.w : n2.y, xf = nx ? n2.y : n3.w;
         const uint32_t yn = ny ? n4.y : n2.w, yf = ny ? n2.w : n4.y;
         const uint32_t zn = nz ? n4.w : n3.y, zf = nz ? n3.y : n4.w;
-        const uint32_t meta4 = n1.w;
-        const uint32_t inner4 = ((meta4 & (meta4 << 1)) & 0x10101010u) << 3;
-        const uint32_t index4 = meta4 ^ (oct_inv4 & ((inner4 - (inner4 >> 7)) | inner4));
-        hitmask = wide_child<0>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
-        hitmask = wide_child<1>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
-        hitmask = wide_child<2>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
-        hitmask = wide_child<3>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, meta4, index4, hitmask);
+        hits = wide_child<3>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
+        hits = wide_child<2>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
+        hits = wide_child<1>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
+        hits = wide_child<0>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
     }
-    return hitmask;
+    {
+        const uint32_t xn = nx ? n3.z : n2.x, xf = nx ? n2.x : n3.z;
+        const uint32_t yn = ny ? n4.x : n2.z, yf = ny ? n2.z : n4.x;
+        const uint32_t zn = nz ? n4.z : n3.x, zf = nz ? n3.x : n4.z;
+        hits = wide_child<3>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
+        hits = wide_child<2>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
+        hits = wide_child<1>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
+        hits = wide_child<0>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
+    }
+    return hits;
+}
+
+// Bits of a byte moved from position s to position s ^ c: one conditional exchange per bit of c
+// (neighbours, pairs, halves).  `swaps` holds the three exchange masks of the ray's c - 0x55,
+// 0x33, 0x0f where the bit of c is set, else 0 - in its bytes 0, 1, 2.
+RTX_DEV uint32_t exchange_slots(uint32_t x, uint32_t swaps) {
+    uint32_t t = ((x >> 1) ^ x) & (swaps & 0xffu);
+    x ^= t + (t << 1);
+    t = ((x >> 2) ^ x) & ((swaps >> 8) & 0xffu);
+    x ^= t + (t << 2);
+    t = ((x >> 4) ^ x) & ((swaps >> 16) & 0xffu);
+    x ^= t + (t << 4);
+    return x;
 }
 
 // BVH scenes, fast mode: the same pool of (pixel, sample) items per wave, but traversal and
@@ -1860,9 +1869,11 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
     ps.rng.state = 0;
     ps.rng.inc = 1;
     // The query in flight.  A node group is the children of one node that the ray still has to
-    // visit: the index of the node's first inner child and (hit bits << 24 | the node's imask);
-    // an item group the leaf records still to test: the node's item_base and their bits.
-    uint32_t ng_base = 0u, ng_bits = 0u, ig_base = 0u, ig_bits = 0u, oct_inv4 = 0u;
+    // visit: the index of the node's first inner child and (hit bits in visiting order << 24 | the
+    // node's imask); an item group the leaf slots still to test: the node and their slot bits.
+    // `order`: c = 7 - octant(ray) in its top byte (slots are visited in descending order of
+    // slot ^ c), the exchange masks of c below (exchange_slots).
+    uint32_t ng_base = 0u, ng_bits = 0u, ig_node = 0u, ig_bits = 0u, order = 0u;
     uint32_t sp = 0, best = kNone;
     float closest = kFltMax;
     V3 inv = v3(0.0f, 0.0f, 0.0f), noi = inv;
@@ -1960,7 +1971,8 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 if constexpr (kWide) {  // slots are visited in ascending order of slot ^ octant: 7 - octant in every byte
                     const uint32_t oct = (__float_as_uint(inv.x) >> 31) | ((__float_as_uint(inv.y) >> 31) << 1) |
                                          ((__float_as_uint(inv.z) >> 31) << 2);
-                    oct_inv4 = (7u - oct) * 0x01010101u;
+                    const uint32_t c = 7u - oct;
+                    order = (c << 24) | ((c & 1u) ? 0x55u : 0u) | ((c & 2u) ? 0x3300u : 0u) | ((c & 4u) ? 0x0f0000u : 0u);
                     ng_base = 0u;  // the root as the one child of a group without inner-node mask: node 0
                     ng_bits = 0x80000000u;
                     ig_bits = 0u;
@@ -2011,27 +2023,37 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     // the pending child the ray wants first: the highest hit bit
                     const uint32_t bit = 31u - (uint32_t)__clz((int)ng_bits);
                     ng_bits ^= 1u << bit;
-                    const uint32_t slot = (bit - 24u) ^ (oct_inv4 & 7u);
+                    const uint32_t slot = (bit - 24u) ^ (order >> 24);
                     const uint32_t node = ng_base + (uint32_t)__popc(ng_bits & ((1u << slot) - 1u));  // inner slots below it
                     if (ng_bits & 0xff000000u) {  // siblings left: they wait on the stack
                         s_stack[sp][tid] = make_uint2(ng_base, ng_bits);
                         ++sp;
                     }
                     const uint4* p = reinterpret_cast<const uint4*>(sc.bvh_wide + node);
-                    const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
-                    const uint32_t hitmask = wide_node_hits(n0, n1, n2, n3, n4, inv, noi, oct_inv4, kTMin, closest);
-                    RTX_STAT(11, (uint32_t)__popcll(__ballot(hitmask == 0u)));  // [11] node steps that met no child
-                    RTX_STAT(10, (uint32_t)__popcll(__ballot(hitmask == 0u && best != kNone)));  // [10] ... with a hit in hand
-                    ng_base = n1.x;
-                    ng_bits = (hitmask & 0xff000000u) | (n0.w >> 24);
-                    ig_base = n1.y;
-                    ig_bits = hitmask & 0x00ffffffu;
+                    const uint4 n0 = p[0], n2 = p[2], n3 = p[3], n4 = p[4];
+                    const uint32_t child_base = reinterpret_cast<const uint32_t*>(p)[4];
+                    const uint32_t hits = wide_node_hits(n0, n2, n3, n4, inv, noi, kTMin, closest);
+                    RTX_STAT(11, (uint32_t)__popcll(__ballot(hits == 0u)));  // [11] node steps that met no child
+                    RTX_STAT(10, (uint32_t)__popcll(__ballot(hits == 0u && best != kNone)));  // [10] ... with a hit in hand
+                    const uint32_t imask = n0.w >> 24;
+                    ng_base = child_base;
+                    ng_bits = (exchange_slots(hits & imask, order) << 24) | imask;
+                    ig_node = node;
+                    ig_bits = hits & ~imask;
                     if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
                 }
                 if (leaves_now && at_leaf) {
+                    // the slot's meta byte (unary item count << 5 | first item's offset from item_base)
+                    // is read from the node again: per ray there are ten node steps to one leaf
                     const uint32_t k = (uint32_t)__ffs((int)ig_bits) - 1u;
                     ig_bits &= ig_bits - 1u;
-                    fast_leaf_item(sc, sc.wide_items[ig_base + k], ps.o, ps.d, inv, noi, kTMin, closest, best);
+                    const uint4 n1 = reinterpret_cast<const uint4*>(sc.bvh_wide + ig_node)[1];
+                    const uint32_t meta = ((k < 4u ? n1.z : n1.w) >> (8u * (k & 3u))) & 0xffu;
+                    uint32_t first = n1.y + (meta & 31u), left = (uint32_t)__popc(meta >> 5);
+                    do {
+                        fast_leaf_item(sc, sc.wide_items[first], ps.o, ps.d, inv, noi, kTMin, closest, best);
+                        ++first;
+                    } while (--left != 0u);
                     if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
                 }
             } else {
