@@ -143,6 +143,11 @@ RTX_DEV V3 qrotate(float qx, float qy, float qz, float qw, V3 v) {
               (((tw * qz) + (tz * qw)) - (tx * qy)) + (ty * qx)};
 }
 
+// The lanes of the wave for which `pred` holds.  (HIP's __ballot takes an int: the predicate is
+// first turned into 0 / 1 per lane and then compared with 0 again - two vector instructions per
+// ballot; the builtin reads the condition mask itself.)
+RTX_DEV unsigned long long rtx_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
 // Wave-uniform record fetch: the index is the same in every lane, so tell the
 // compiler (scalar loads, SGPR operands).
 template <typename T>
@@ -1575,7 +1580,7 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
 #endif
 
     for (;;) {
-        const unsigned long long want = __ballot(!active);
+        const unsigned long long want = rtx_ballot(!active);
         if (want != 0ull && next < total) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32),
                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
@@ -1625,7 +1630,7 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
         // (no lane with an item although the pool is not spent: only slots outside the image were
         // drawn on a ragged edge tile; the body below is harmless without items and the loop
         // keeps a single back edge)
-        if (__ballot(active) == 0ull && next >= total) break;
+        if (rtx_ballot(active) == 0ull && next >= total) break;
         // Linear scan: no branch around the body.  A lane without an item (only while the pool
         // drains, or on a ragged edge tile) follows whatever ray it holds and its results are
         // thrown away; what that costs is nothing the wave would not execute anyway, and the
@@ -1642,8 +1647,8 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
             // it only pays when no lane needs it; the tree rejects such a ray at its root anyway).
             // Only camera rays come from outside the scene: the test runs when every ray of the wave is one.
             bool hit = false;
-            bool scan = kBvh || __ballot(active && ps.depth != 0u) != 0ull;
-            if (!scan) scan = __ballot(active && ray_meets_scene(sc, ps.o, ps.d, kTMin)) != 0ull;
+            bool scan = kBvh || rtx_ballot(active && ps.depth != 0u) != 0ull;
+            if (!scan) scan = rtx_ballot(active && ray_meets_scene(sc, ps.o, ps.d, kTMin)) != 0ull;
             if (scan) hit = scene_query<kBvh>(sc, ps.o, ps.d, kTMin, kFltMax, t_hit, prim_hit);
 #endif
             ++segs;
@@ -1898,9 +1903,9 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
     } while (0)
 
     for (;;) {
-        const unsigned long long walking = __ballot(phase == kWalk);
-        const uint32_t n_done = (uint32_t)__popcll(__ballot(phase == kDoneWalk));
-        const unsigned long long idle = __ballot(phase == kIdle);
+        const unsigned long long walking = rtx_ballot(phase == kWalk);
+        const uint32_t n_done = (uint32_t)__popcll(rtx_ballot(phase == kDoneWalk));
+        const unsigned long long idle = rtx_ballot(phase == kIdle);
         const bool pool_left = next < total;
         const uint32_t waiting = n_done + (pool_left ? (uint32_t)__popcll(idle) : 0u);
         constexpr uint32_t kShadeBatch = kWide ? RTX_SHADE_BATCH : RTX_SHADE_BATCH2;
@@ -1939,7 +1944,7 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     phase = kNewRay;
                 }
             }
-            const unsigned long long want = __ballot(phase == kIdle);
+            const unsigned long long want = rtx_ballot(phase == kIdle);
             if (want != 0ull && next < total) {  // idle lanes draw the next items of the pool
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32),
                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
@@ -1990,7 +1995,7 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 phase = kWalk;
             }
         }
-        if (__ballot(phase != kIdle) == 0ull) {
+        if (rtx_ballot(phase != kIdle) == 0ull) {
             if (next >= total) break;  // pool spent, nothing in flight
             continue;                  // this draw fell outside the image (ragged tile): draw again
         }
@@ -2001,13 +2006,18 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
             // node group one node down.  Lanes with items hold them until kLeafBatch of them have
             // some (or nobody is left at a node), so that the leaf code - four record types, each
             // its own branch - runs on a fuller wave.
-            const bool at_leaf = phase == kWalk && (kWide ? ig_bits != 0u : (ref & kBvhLeaf) != 0u);
+            // (each ballot is of ONE comparison - its condition mask is the ballot - and the masks are
+            // combined on the scalar unit: the ballot of a compound condition costs two more vector
+            // instructions, which turn the combined mask into 0 / 1 per lane and compare that again)
+            const bool holds_items = kWide ? ig_bits != 0u : (ref & kBvhLeaf) != 0u;
+            const bool at_leaf = phase == kWalk && holds_items;
             const bool at_node = phase == kWalk && !at_leaf;
-            const unsigned long long nodes = __ballot(at_node);
-            const uint32_t n_leaves = (uint32_t)__popcll(__ballot(at_leaf));
+            const unsigned long long walk_mask = rtx_ballot(phase == kWalk), item_mask = rtx_ballot(holds_items);
+            const unsigned long long nodes = walk_mask & ~item_mask;
+            const uint32_t n_leaves = (uint32_t)__popcll(walk_mask & item_mask);
             if (nodes == 0ull && n_leaves == 0u) break;
-            RTX_STAT(7, (uint32_t)__popcll(__ballot(phase == kDoneWalk)));  // [7] lanes waiting to be shaded
-            RTX_STAT(8, (uint32_t)__popcll(__ballot(phase == kIdle)));      // [8] lanes without an item
+            RTX_STAT(7, (uint32_t)__popcll(rtx_ballot(phase == kDoneWalk)));  // [7] lanes waiting to be shaded
+            RTX_STAT(8, (uint32_t)__popcll(rtx_ballot(phase == kIdle)));      // [8] lanes without an item
             RTX_STAT(9, n_leaves);                                           // [9] lanes holding leaf items
             if (nodes != 0ull) {
                 RTX_STAT(0, 1u);                            // [0] node steps of the wave
@@ -2033,8 +2043,8 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     const uint4 n0 = p[0], n2 = p[2], n3 = p[3], n4 = p[4];
                     const uint32_t child_base = reinterpret_cast<const uint32_t*>(p)[4];
                     const uint32_t hits = wide_node_hits(n0, n2, n3, n4, inv, noi, kTMin, closest);
-                    RTX_STAT(11, (uint32_t)__popcll(__ballot(hits == 0u)));  // [11] node steps that met no child
-                    RTX_STAT(10, (uint32_t)__popcll(__ballot(hits == 0u && best != kNone)));  // [10] ... with a hit in hand
+                    RTX_STAT(11, (uint32_t)__popcll(rtx_ballot(hits == 0u)));  // [11] node steps that met no child
+                    RTX_STAT(10, (uint32_t)__popcll(rtx_ballot(hits == 0u && best != kNone)));  // [10] ... with a hit in hand
                     const uint32_t imask = n0.w >> 24;
                     ng_base = child_base;
                     ng_bits = (exchange_slots(hits & imask, order) << 24) | imask;
