@@ -818,12 +818,12 @@ RTX_DEV bool query_bvh(const SceneView& sc, V3 o, V3 d, float t0, float t1, floa
                 float n0, n1;
                 const bool h0 = slab(N.a.x, N.a.y, N.a.z, br, t0, closest, n0);
                 const bool h1 = slab(N.a.w, N.b.x, N.b.y, br, t0, closest, n1);
-                if (h0 & h1) {
+                if (h0 && h1) {
                     const bool first0 = n0 <= n1;
                     if (sp < (uint32_t)kBvhStack) s_stack[sp][tid] = first0 ? N.b.w : N.b.z;
                     ++sp;
                     ref = first0 ? N.b.z : N.b.w;
-                } else if (h0 | h1) {
+                } else if (h0 || h1) {
                     ref = h0 ? N.b.z : N.b.w;
                 } else {
                     ref = pop_ref(s_stack, sp, tid);
@@ -2072,12 +2072,12 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     float n0, n1;
                     const bool h0 = slab_signed(N.a.x, N.a.y, N.a.z, br, kTMin, closest, n0);
                     const bool h1 = slab_signed(N.a.w, N.b.x, N.b.y, br, kTMin, closest, n1);
-                    if (h0 & h1) {  // the nearer child first, the other waits on the stack
+                    if (h0 && h1) {  // the nearer child first, the other waits on the stack
                         const bool first0 = n0 <= n1;
                         if (sp < (uint32_t)kBvhStack) s_stack2[sp][tid] = first0 ? N.b.w : N.b.z;
                         ++sp;
                         ref = first0 ? N.b.z : N.b.w;
-                    } else if (h0 | h1) {
+                    } else if (h0 || h1) {
                         ref = h0 ? N.b.z : N.b.w;
                     } else {
                         ref = pop_ref(s_stack2, sp, tid);
