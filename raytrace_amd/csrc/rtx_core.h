@@ -1581,6 +1581,10 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
 
     for (;;) {
         const unsigned long long want = rtx_ballot(!active);
+        // (all 64 lanes of the wave are here; with the pool spent nothing below can start a path.  A
+        // draw that found only slots outside the image - a ragged edge tile - costs one more turn of
+        // the harmless body before this test sees it.)
+        if (want == ~0ull && next >= total) break;
         if (want != 0ull && next < total) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32),
                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
@@ -1630,7 +1634,6 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
         // (no lane with an item although the pool is not spent: only slots outside the image were
         // drawn on a ragged edge tile; the body below is harmless without items and the loop
         // keeps a single back edge)
-        if (rtx_ballot(active) == 0ull && next >= total) break;
         // Linear scan: no branch around the body.  A lane without an item (only while the pool
         // drains, or on a ragged edge tile) follows whatever ray it holds and its results are
         // thrown away; what that costs is nothing the wave would not execute anyway, and the
@@ -1647,7 +1650,9 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
             // it only pays when no lane needs it; the tree rejects such a ray at its root anyway).
             // Only camera rays come from outside the scene: the test runs when every ray of the wave is one.
             bool hit = false;
-            bool scan = kBvh || rtx_ballot(active && ps.depth != 0u) != 0ull;
+            // (the lanes that held a path before this turn's draw are those outside `want`, the paths
+            // drawn just now are at depth 0: one ballot of one comparison)
+            bool scan = kBvh || (rtx_ballot(ps.depth != 0u) & ~want) != 0ull;
             if (!scan) scan = rtx_ballot(active && ray_meets_scene(sc, ps.o, ps.d, kTMin)) != 0ull;
             if (scan) hit = scene_query<kBvh>(sc, ps.o, ps.d, kTMin, kFltMax, t_hit, prim_hit);
 #endif
