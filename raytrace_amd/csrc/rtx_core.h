@@ -1014,14 +1014,18 @@ RTX_DEV float cone_cosine(float rr, float dd) {
 #endif
 }
 
+// kListLit (here and below): the caller knows that the light shape is a list with at least one entry
+// and that the background is a constant colour - what the reference's own scene is (Scene.cpp:83-86,
+// Scene.cpp:131).  The wave-uniform tests for it then need no registers across the kernel's loop.
+template <bool kListLit = false>
 RTX_DEV V3 sample_direction(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
     uint32_t kind = kSampleCosine;
     Light E;
     E.a = E.b = E.c = E.d = E.e = 0.0f;
     // no light shape: the material's own pdf alone, without the mixture's draw (wave-uniform)
-    if (sc.n_lights != 0u && rng_nextf(&rng) < 0.5f) {
+    if ((kListLit || sc.n_lights != 0u) && rng_nextf(&rng) < 0.5f) {
         uint32_t index = 0;
-        if (sc.light_is_list) {
+        if (kListLit || sc.light_is_list) {
             float r = rng_nextf(&rng);
             index = (uint32_t)(r * (float)sc.n_lights);
             if (index >= sc.n_lights) index = sc.n_lights - 1;
@@ -1123,8 +1127,9 @@ RTX_DEV float light_pdf_one_fast(const Light& E, V3 o, V3 v, float len2, float i
     return 0.0f;
 }
 
+template <bool kListLit = false>
 RTX_DEV float light_pdf_fast(const SceneView& sc, V3 o, V3 v, float len2, float inv_len) {
-    if (!sc.light_is_list) return light_pdf_one_fast(load_uniform(sc.lights, 0u), o, v, len2, inv_len);
+    if (!kListLit && !sc.light_is_list) return light_pdf_one_fast(load_uniform(sc.lights, 0u), o, v, len2, inv_len);
     float sum = 0.0f;
     for (uint32_t k = 0; k < sc.n_lights; ++k) sum += light_pdf_one_fast(load_uniform(sc.lights, k), o, v, len2, inv_len);
     return sum * frcp((float)sc.n_lights);
@@ -1334,12 +1339,12 @@ RTX_DEV bool pin(PathState& ps) {
     return true;
 }
 
-template <bool kLightTree>
+template <bool kLightTree, bool kListLit = false>
 RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitRec& rec, PathState& ps,
                    V3& L) {
     if (!hit) {  // Scene.cpp:131
         V3 bg = v3(sc.background);
-        if (sc.background_mode == RTX_BACKGROUND_SKY) {  // Scene::backgroundSky, Scene.h:24-28
+        if (!kListLit && sc.background_mode == RTX_BACKGROUND_SKY) {  // Scene::backgroundSky, Scene.h:24-28
             const V3 v = normalize(ps.d);
             const float t = 0.5f * (v.y + 1.0f);
             const V3 white = v3(1.0f, 1.0f, 1.0f);
@@ -1362,14 +1367,14 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
     if (mat_kind == RTX_MAT_LAMBERTIAN) {
         V3 albedo = surface_color(sc, rec);  // Lambertian.cpp:17
         const V3 dir = kLightTree ? sample_direction_tree(sc, rec.p, rec.n, ps.rng)
-                                  : sample_direction(sc, rec.p, rec.n, ps.rng);
+                                  : sample_direction<kListLit>(sc, rec.p, rec.n, ps.rng);
 #if !RTX_DET
         if (!kLightTree) {  // the same estimator with 1 / |dir| shared between the densities
             const float len2 = dot(dir, dir), inv_len = finvsqrt(len2);
             const float cosine = dot(dir, rec.n) * inv_len;
             const float pdf1 = (cosine > 0.0f ? cosine : 0.0f) * (1.0f / kPi);  // = the scattering pdf
             const float pdf_value =
-                sc.n_lights != 0u ? 0.5f * light_pdf_fast(sc, rec.p, dir, len2, inv_len) + 0.5f * pdf1 : pdf1;
+                (kListLit || sc.n_lights != 0u) ? 0.5f * light_pdf_fast<kListLit>(sc, rec.p, dir, len2, inv_len) + 0.5f * pdf1 : pdf1;
             // the next ray is committed before the test: a path that ends here has no use for the
             // old one either, and the old one's registers are free from this point on
             ps.o = rec.p;
@@ -1519,7 +1524,7 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
 // pixel slot l to HBM once, at the end.  Only this wave touches its slice of LDS, and the wave
 // executes in lockstep, so the order of the adds - and with it every bit of the result -
 // is reproducible from run to run.
-template <bool kBvh, bool kSamples, bool kLightTree>
+template <bool kBvh, bool kSamples, bool kLightTree, bool kListLit = false>
 // 96 scalar registers per wave: a SIMD's scalar register file holds eight waves of that size; at
 // the 106 the kernel would take by itself the ninth-to-sixth waves do not fit, whatever the vector
 // registers allow (measured: 83.6 -> 85.2 Grays/s on the Cornell box).
@@ -1662,11 +1667,11 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
             if (hit) {  // the winner's record lives inside this branch only
                 HitRec rec;
                 scene_finish<kBvh>(sc, prim_hit, t_hit, ps.o, ps.d, false, rec);
-                ended = shade<kLightTree>(sc, a.max_depth, true, rec, ps, L);
+                ended = shade<kLightTree, kListLit>(sc, a.max_depth, true, rec, ps, L);
             } else {
                 HitRec none;
                 none.bits = 0u;
-                ended = shade<kLightTree>(sc, a.max_depth, false, none, ps, L);
+                ended = shade<kLightTree, kListLit>(sc, a.max_depth, false, none, ps, L);
             }
             if (ended && active) {
                 const uint32_t slot = item & pix_mask;
@@ -2064,11 +2069,10 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     ig_bits &= ig_bits - 1u;
                     const uint4 n1 = reinterpret_cast<const uint4*>(sc.bvh_wide + ig_node)[1];
                     const uint32_t meta = ((k < 4u ? n1.z : n1.w) >> (8u * (k & 3u))) & 0xffu;
-                    uint32_t first = n1.y + (meta & 31u), left = (uint32_t)__popc(meta >> 5);
-                    do {
+                    uint32_t first = n1.y + (meta & 31u);
+                    // (an empty slot - count 0 - is never met: its box is inverted; the loop still ends on it)
+                    for (uint32_t left = (uint32_t)__popc(meta >> 5); left != 0u; --left, ++first)
                         fast_leaf_item(sc, sc.wide_items[first], ps.o, ps.d, inv, noi, kTMin, closest, best);
-                        ++first;
-                    } while (--left != 0u);
                     if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
                 }
             } else {
