@@ -562,7 +562,8 @@ RTX_DEV void scan_boxes(const SceneView& sc, uint32_t& pos, uint32_t count, V3 r
 RTX_DEV bool query_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, float& t_hit, uint32_t& prim_hit) {
     float closest = t1;
     uint32_t best = kNone;
-    for (uint32_t g = 0; g < sc.n_scan_groups; ++g) {
+    uint32_t g = 0u;
+    do {  // (the table of an uploaded scene has at least one group: no test before the first)
         const ScanGroup G = load_uniform(sc.scan_groups, g);
         V3 ro = o, rd = d;
         if (G.rot_y) {  // the products with the exact zeros and the one of the map left out
@@ -604,7 +605,7 @@ RTX_DEV bool query_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, f
             }
         }
         if (G.n_box) scan_boxes(sc, pos, G.n_box, ro, aux, t0, closest, best);
-    }
+    } while (++g < sc.n_scan_groups);
     t_hit = closest;
     prim_hit = best;
     return best != kNone;
@@ -1131,7 +1132,13 @@ template <bool kListLit = false>
 RTX_DEV float light_pdf_fast(const SceneView& sc, V3 o, V3 v, float len2, float inv_len) {
     if (!kListLit && !sc.light_is_list) return light_pdf_one_fast(load_uniform(sc.lights, 0u), o, v, len2, inv_len);
     float sum = 0.0f;
-    for (uint32_t k = 0; k < sc.n_lights; ++k) sum += light_pdf_one_fast(load_uniform(sc.lights, k), o, v, len2, inv_len);
+    if (kListLit) {  // at least one entry: no test before the first turn (and no register for its outcome)
+        uint32_t k = 0u;
+        do sum += light_pdf_one_fast(load_uniform(sc.lights, k), o, v, len2, inv_len);
+        while (++k < sc.n_lights);
+    } else {
+        for (uint32_t k = 0; k < sc.n_lights; ++k) sum += light_pdf_one_fast(load_uniform(sc.lights, k), o, v, len2, inv_len);
+    }
     return sum * frcp((float)sc.n_lights);
 }
 #endif
@@ -1529,7 +1536,15 @@ template <bool kBvh, bool kSamples, bool kLightTree, bool kListLit = false>
 // the 106 the kernel would take by itself the ninth-to-sixth waves do not fit, whatever the vector
 // registers allow (measured: 83.6 -> 85.2 Grays/s on the Cornell box).
 __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bounds__(RTX_BLOCK, kBvh ? RTX_TRACE_WAVES_BVH : RTX_TRACE_WAVES) trace_kernel(const TraceArgs a) {
-    __shared__ float s_acc[RTX_BLOCK / 64][3][64];
+    // One block of LDS per wave - the pixel sums and (fast mode) the per-slot start-up data - so that one
+    // scalar register holds the base of both.
+    struct alignas(16) WaveLds {
+#if !RTX_DET
+        uint4 slot[64];
+#endif
+        float acc[3][64];
+    };
+    __shared__ WaveLds s_wave[RTX_BLOCK / 64];
 #ifdef RTX_PROBE_LDS_BYTES  // occupancy experiments: LDS ballast that caps the resident blocks per CU
     __shared__ float s_ballast[RTX_PROBE_LDS_BYTES / 4];
     if (a.width == 0xffffffffu) s_ballast[threadIdx.x] = 1.0f;
@@ -1547,15 +1562,14 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
     if (x0 >= a.width || y0 >= a.height) return;  // wave-uniform
     const uint32_t tw = min(tile_w, a.width - x0), th = min(tile_h, a.height - y0);
 
-    s_acc[wave][0][lane] = 0.0f;
-    s_acc[wave][1][lane] = 0.0f;
-    s_acc[wave][2][lane] = 0.0f;
+    s_wave[wave].acc[0][lane] = 0.0f;
+    s_wave[wave].acc[1][lane] = 0.0f;
+    s_wave[wave].acc[2][lane] = 0.0f;
 #if !RTX_DET
     // What a new item needs of its pixel - the stream key, the coordinates as floats, whether the
     // slot lies inside the image - is the same for all the samples of the pixel: lane l works it
     // out once for slot l, and starting an item costs one 16-byte LDS read instead of a hash, an
     // integer multiply-add and two conversions.
-    __shared__ uint4 s_slot[RTX_BLOCK / 64][64];
     const float inv_nx = frcp((float)a.width), inv_ny = frcp((float)a.height);
     {
         const uint32_t sx = lane & (tile_w - 1u), sy = lane >> twl;
@@ -1566,7 +1580,7 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
         const float u0 = (float)i * inv_nx, v0 = (float)j * inv_ny;
         const V3 corner = ((v3(sc.cam_ll) - v3(sc.cam_origin)) + v3(sc.cam_u) * u0) + v3(sc.cam_v) * v0;
         const uint32_t key = rng_pixel_key(j * a.width + i, a.seed);
-        s_slot[wave][lane] = make_uint4(inside ? (key != 0u ? key : 1u) : 0u, __float_as_uint(corner.x),
+        s_wave[wave].slot[lane] = make_uint4(inside ? (key != 0u ? key : 1u) : 0u, __float_as_uint(corner.x),
                                         __float_as_uint(corner.y), __float_as_uint(corner.z));
     }
 #endif
@@ -1605,7 +1619,7 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
                     rng_init(&ps.rng, j * a.width + i, a.spp_begin + (mine >> pixl), a.seed);
                     const float fi = (float)i, fj = (float)j;
 #else
-                const uint4 slot_info = s_slot[wave][slot];
+                const uint4 slot_info = s_wave[wave].slot[slot];
                 if (slot_info.x != 0u) {  // 0: the slot lies outside the image
                     item = mine;
                     rng_init_keyed(&ps.rng, slot_info.x, a.spp_begin + (mine >> pixl));
@@ -1675,9 +1689,9 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
             }
             if (ended && active) {
                 const uint32_t slot = item & pix_mask;
-                atomicAdd(&s_acc[wave][0][slot], L.x);  // Scene.cpp:148
-                atomicAdd(&s_acc[wave][1][slot], L.y);
-                atomicAdd(&s_acc[wave][2][slot], L.z);
+                atomicAdd(&s_wave[wave].acc[0][slot], L.x);  // Scene.cpp:148
+                atomicAdd(&s_wave[wave].acc[1][slot], L.y);
+                atomicAdd(&s_wave[wave].acc[2][slot], L.z);
                 rays += segs;
                 if (kSamples) {
                     const uint32_t i = x0 + (slot & (tile_w - 1u)), j = y0 + (slot >> twl);
@@ -1697,7 +1711,7 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
     if (a.accum && sx < tw && sy < th) {
         const uint32_t i = x0 + sx, j = y0 + sy;
         float* out = a.accum + ((size_t)(a.height - 1u - j) * a.width + i) * 3u;  // Scene.cpp:151
-        const float r = s_acc[wave][0][lane], g = s_acc[wave][1][lane], b = s_acc[wave][2][lane];
+        const float r = s_wave[wave].acc[0][lane], g = s_wave[wave].acc[1][lane], b = s_wave[wave].acc[2][lane];
         if (a.accumulate) {
             out[0] += r;
             out[1] += g;
