@@ -1028,8 +1028,7 @@ RTX_DEV V3 sample_direction(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
         uint32_t index = 0;
         if (kListLit || sc.light_is_list) {
             float r = rng_nextf(&rng);
-            index = (uint32_t)(r * (float)sc.n_lights);
-            if (index >= sc.n_lights) index = sc.n_lights - 1;
+            index = min((uint32_t)(r * (float)sc.n_lights), sc.n_lights - 1u);
         }
         E = sc.lights[index];  // per-lane
         kind = E.kind;
@@ -1553,7 +1552,8 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t twl = a.tile_w_log2, pixl = a.tile_w_log2 + a.tile_h_log2;  // this wave's pixel tile
-    const uint32_t tile_w = 1u << twl, tile_h = 1u << a.tile_h_log2, pix_mask = (1u << pixl) - 1u;
+    const uint32_t tile_w = 1u << twl, tile_h = 1u << a.tile_h_log2;
+    [[maybe_unused]] const uint32_t pix_mask = (1u << pixl) - 1u;
     constexpr uint32_t kSide = RTX_BLOCK == 256 ? 2u : 1u;  // waves per block edge
     const uint32_t tiles_x = (a.width + kSide * tile_w - 1u) / (kSide * tile_w);
     const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
@@ -1610,7 +1610,7 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
             const uint32_t mine = next + rank;
             next += (uint32_t)__popcll(want);
             if (!active && mine < total) {
-                const uint32_t slot = mine & pix_mask;
+                const uint32_t slot = __builtin_amdgcn_ubfe(mine, 0u, pixl);  // mine & pix_mask from the one register that also shifts
 #if RTX_DET
                 const uint32_t sx = slot & (tile_w - 1u), sy = slot >> twl;
                 if (sx < tw && sy < th) {
@@ -1688,7 +1688,7 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
                 ended = shade<kLightTree, kListLit>(sc, a.max_depth, false, none, ps, L);
             }
             if (ended && active) {
-                const uint32_t slot = item & pix_mask;
+                const uint32_t slot = __builtin_amdgcn_ubfe(item, 0u, pixl);
                 atomicAdd(&s_wave[wave].acc[0][slot], L.x);  // Scene.cpp:148
                 atomicAdd(&s_wave[wave].acc[1][slot], L.y);
                 atomicAdd(&s_wave[wave].acc[2][slot], L.z);
