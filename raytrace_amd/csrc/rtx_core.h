@@ -1571,6 +1571,10 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
     // out once for slot l, and starting an item costs one 16-byte LDS read instead of a hash, an
     // integer multiply-add and two conversions.
     const float inv_nx = frcp((float)a.width), inv_ny = frcp((float)a.height);
+    // one pixel's step along the two image axes (wave-uniform: back into scalar registers)
+    const auto uniform = [](float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
+    const V3 pixel_u = v3(uniform(sc.cam_u[0] * inv_nx), uniform(sc.cam_u[1] * inv_nx), uniform(sc.cam_u[2] * inv_nx));
+    const V3 pixel_v = v3(uniform(sc.cam_v[0] * inv_ny), uniform(sc.cam_v[1] * inv_ny), uniform(sc.cam_v[2] * inv_ny));
     {
         const uint32_t sx = lane & (tile_w - 1u), sy = lane >> twl;
         const uint32_t i = x0 + sx, j = y0 + sy;
@@ -1623,11 +1627,14 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
                 if (slot_info.x != 0u) {  // 0: the slot lies outside the image
                     item = mine;
                     rng_init_keyed(&ps.rng, slot_info.x, a.spp_begin + (mine >> pixl));
-                    const float du = rng_nextf(&ps.rng) * inv_nx;  // Scene.cpp:145-146: u first, then v
-                    const float dv = rng_nextf(&ps.rng) * inv_ny;
+                    const float du = rng_nextf(&ps.rng);  // Scene.cpp:145-146: u first, then v
+                    const float dv = rng_nextf(&ps.rng);
                     ps.o = v3(sc.cam_origin);
+                    // (the origin from here on as the vector registers just written, not as three scalar
+                    // operands again: an instruction with a scalar operand issues at half rate)
+                    asm("" : "+v"(ps.o.x), "+v"(ps.o.y), "+v"(ps.o.z));
                     ps.d = (v3(__uint_as_float(slot_info.y), __uint_as_float(slot_info.z), __uint_as_float(slot_info.w)) +
-                            v3(sc.cam_u) * du) + v3(sc.cam_v) * dv;
+                            pixel_u * du) + pixel_v * dv;
                     // The reference forms the direction as (lower-left + ...) - origin (Camera.h:24-26),
                     // i.e. it rounds the point on the image plane in WORLD coordinates before it
                     // subtracts the origin, which puts the directions on a grid of one ulp of those
