@@ -2102,15 +2102,19 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     float n0, n1;
                     const bool h0 = slab_signed(N.a.x, N.a.y, N.a.z, br, kTMin, closest, n0);
                     const bool h1 = slab_signed(N.a.w, N.b.x, N.b.y, br, kTMin, closest, n1);
+                    // (rtx_upload_scene refuses a tree deeper than the stack: no bounds test here)
                     if (h0 && h1) {  // the nearer child first, the other waits on the stack
                         const bool first0 = n0 <= n1;
-                        if (sp < (uint32_t)kBvhStack) s_stack2[sp][tid] = first0 ? N.b.w : N.b.z;
+                        s_stack2[sp][tid] = first0 ? N.b.w : N.b.z;
                         ++sp;
                         ref = first0 ? N.b.z : N.b.w;
                     } else if (h0 || h1) {
                         ref = h0 ? N.b.z : N.b.w;
+                    } else if (sp != 0u) {
+                        --sp;
+                        ref = s_stack2[sp][tid];
                     } else {
-                        ref = pop_ref(s_stack2, sp, tid);
+                        ref = kDone;
                     }
                     if (ref == kDone) phase = kDoneWalk;
                 }
@@ -2118,7 +2122,12 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     const uint32_t first = ref & kBvhLeafFirst, count = (ref >> kBvhLeafCountShift) & 15u;
                     for (uint32_t k = 0; k < count; ++k)
                         fast_leaf_item(sc, sc.bvh_fast[first + k], ps.o, ps.d, inv, noi, kTMin, closest, best);
-                    ref = pop_ref(s_stack2, sp, tid);
+                    if (sp != 0u) {
+                        --sp;
+                        ref = s_stack2[sp][tid];
+                    } else {
+                        ref = kDone;
+                    }
                     if (ref == kDone) phase = kDoneWalk;
                 }
             }
