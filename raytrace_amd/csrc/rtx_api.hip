@@ -737,6 +737,11 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
         }
     }
 
+    // the kernels address these tables per lane with 32-bit byte offsets
+    if (scan_info.size() * sizeof(rtxd::ScanHit) >= (1ull << 32) || fast_items.size() * sizeof(rtxd::BvhFastItem) >= (1ull << 32) ||
+        tree.wide.size() * sizeof(rtxd::WideNode) >= (1ull << 32) || nodes.size() * sizeof(rtxd::BvhNode) >= (1ull << 32) ||
+        lights.size() * sizeof(rtxd::Light) >= (1ull << 32))
+        return fail(RTX_ERR_TOO_LARGE, "a scene table exceeds 4 GiB");
     RTX_HIP(ctx->prims.upload(prims_padded));
     RTX_HIP(ctx->prim_info.upload(info));
     RTX_HIP(ctx->groups.upload(groups));

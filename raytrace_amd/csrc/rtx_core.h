@@ -148,6 +148,15 @@ RTX_DEV V3 qrotate(float qx, float qy, float qz, float qw, V3 v) {
 // ballot; the builtin reads the condition mask itself.)
 RTX_DEV unsigned long long rtx_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 
+// Record i of a table, addressed per lane with a 32-bit byte offset: the load then takes the table's
+// base from a scalar register pair and the offset from one vector register, and the lane does no
+// 64-bit address arithmetic (a 64-bit shift and a 64-bit add per load otherwise).  The upload keeps
+// every table addressed this way below 4 GiB.
+template <typename T>
+RTX_DEV const T& at32(const T* base, uint32_t i) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (uint32_t)(i * (uint32_t)sizeof(T)));
+}
+
 // Wave-uniform record fetch: the index is the same in every lane, so tell the
 // compiler (scalar loads, SGPR operands).
 template <typename T>
@@ -446,7 +455,7 @@ RTX_DEV uint32_t original_prim(const SceneView&, uint32_t prim, bool) { return p
 // world space, no transform.  `slot` is a position of scan_info / scan_orig.
 template <bool kBvh>
 RTX_DEV void finish_scan_hit(const SceneView& sc, uint32_t slot, float t, V3 o, V3 d, bool want_uv, HitRec& rec) {
-    const ScanHit I = sc.scan_info[slot];
+    const ScanHit I = at32(sc.scan_info, slot);
     const V3 p = o + d * t;
     const V3 pc = p - v3(I.c);
     rec.t = t;
@@ -696,7 +705,7 @@ struct NodeWords {
     uint4 a, b;  // a.xyz: child 0's box, a.w | b.xy: child 1's box, b.z / b.w: the children
 };
 RTX_DEV NodeWords load_node(const SceneView& sc, uint32_t ref) {
-    const uint4* p = reinterpret_cast<const uint4*>(sc.bvh + ref);
+    const uint4* p = reinterpret_cast<const uint4*>(&at32(sc.bvh, ref));
     NodeWords n;
     n.a = p[0];
     n.b = p[1];
@@ -1030,7 +1039,7 @@ RTX_DEV V3 sample_direction(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
             float r = rng_nextf(&rng);
             index = min((uint32_t)(r * (float)sc.n_lights), sc.n_lights - 1u);
         }
-        E = sc.lights[index];  // per-lane
+        E = at32(sc.lights, index);  // per-lane
         kind = E.kind;
     }
     const bool is_sphere = kind == RTX_LIGHT_SPHERE;
@@ -2070,7 +2079,7 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                         s_stack[sp][tid] = make_uint2(ng_base, ng_bits);
                         ++sp;
                     }
-                    const uint4* p = reinterpret_cast<const uint4*>(sc.bvh_wide + node);
+                    const uint4* p = reinterpret_cast<const uint4*>(&at32(sc.bvh_wide, node));
                     const uint4 n0 = p[0], n2 = p[2], n3 = p[3], n4 = p[4];
                     const uint32_t child_base = reinterpret_cast<const uint32_t*>(p)[4];
                     const uint32_t hits = wide_node_hits(n0, n2, n3, n4, inv, noi, kTMin, closest);
@@ -2088,12 +2097,12 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     // is read from the node again: per ray there are ten node steps to one leaf
                     const uint32_t k = (uint32_t)__ffs((int)ig_bits) - 1u;
                     ig_bits &= ig_bits - 1u;
-                    const uint4 n1 = reinterpret_cast<const uint4*>(sc.bvh_wide + ig_node)[1];
+                    const uint4 n1 = reinterpret_cast<const uint4*>(&at32(sc.bvh_wide, ig_node))[1];
                     const uint32_t meta = ((k < 4u ? n1.z : n1.w) >> (8u * (k & 3u))) & 0xffu;
                     uint32_t first = n1.y + (meta & 31u);
                     // (an empty slot - count 0 - is never met: its box is inverted; the loop still ends on it)
                     for (uint32_t left = (uint32_t)__popc(meta >> 5); left != 0u; --left, ++first)
-                        fast_leaf_item(sc, sc.wide_items[first], ps.o, ps.d, inv, noi, kTMin, closest, best);
+                        fast_leaf_item(sc, at32(sc.wide_items, first), ps.o, ps.d, inv, noi, kTMin, closest, best);
                     if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
                 }
             } else {
@@ -2121,7 +2130,7 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 if (leaves_now && at_leaf) {
                     const uint32_t first = ref & kBvhLeafFirst, count = (ref >> kBvhLeafCountShift) & 15u;
                     for (uint32_t k = 0; k < count; ++k)
-                        fast_leaf_item(sc, sc.bvh_fast[first + k], ps.o, ps.d, inv, noi, kTMin, closest, best);
+                        fast_leaf_item(sc, at32(sc.bvh_fast, first + k), ps.o, ps.d, inv, noi, kTMin, closest, best);
                     if (sp != 0u) {
                         --sp;
                         ref = s_stack2[sp][tid];
