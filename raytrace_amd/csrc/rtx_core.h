@@ -754,7 +754,7 @@ RTX_DEV void fast_leaf_item(const SceneView& sc, const BvhFastItem& I, V3 o, V3 
         best = ok ? I.slot : best;
     } else if (type == kBvhItemBox) {
         // the box is [0,1]^3 in the record's frame: plane distances are noi and inv + noi
-        const BvhMap M = sc.bvh_maps[I.map];
+        const BvhMap M = at32(sc.bvh_maps, I.map);
         const float* m = M.m;
         const V3 ro = v3(m[0] * o.x + m[1] * o.y + m[2] * o.z + m[9], m[3] * o.x + m[4] * o.y + m[5] * o.z + m[10],
                          m[6] * o.x + m[7] * o.y + m[8] * o.z + m[11]);
@@ -774,7 +774,7 @@ RTX_DEV void fast_leaf_item(const SceneView& sc, const BvhFastItem& I, V3 o, V3 
         closest = ok ? t : closest;
         best = ok ? I.slot + face : best;
     } else {  // any other transformed group: its primitives one by one in the group's frame
-        const BvhMap M = sc.bvh_maps[I.map];
+        const BvhMap M = at32(sc.bvh_maps, I.map);
         const float* m = M.m;
         const uint32_t first = __float_as_uint(I.f[0]), count = I.type_count >> 8;
         const V3 ro = v3(m[0] * o.x + m[1] * o.y + m[2] * o.z + m[9], m[3] * o.x + m[4] * o.y + m[5] * o.z + m[10],
@@ -783,7 +783,7 @@ RTX_DEV void fast_leaf_item(const SceneView& sc, const BvhFastItem& I, V3 o, V3 
                          m[6] * d.x + m[7] * d.y + m[8] * d.z);
         const RayAux aux = make_aux(ro, rd);
         for (uint32_t k = 0; k < count; ++k) {
-            const Prim P = sc.prims[first + k];
+            const Prim P = at32(sc.prims, first + k);
             float t;
             if (prim_test(P, ro, rd, aux, t0, closest, t)) {
                 closest = t;
