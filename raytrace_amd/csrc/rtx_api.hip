@@ -372,10 +372,11 @@ void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rt
 // instructions of a step down the two-child tree, so it pays when it saves enough steps: by the
 // surface-area estimates of the builder (expected node visits of a ray through the root box), the
 // wide tree is used when the two-child tree needs at least kWideMinVisitRatio times its visits.
-// Measured at 1080p, wide against two-child, Grays/s (ratio of the estimates): 487-sphere field 21.7 /
-// 23.7 (2.52); 200 / 500 / 1 000 / 2 000 / 20 000 items in a slab 46.0 / 46.9 (2.65), 37.6 / 35.9 (2.74),
-// 30.0 / 29.7 (2.83), 25.1 / 23.6 (2.86), 11.6 / 10.5 (2.99); 100 000 items 6.42 / 5.93 (3.04); a 12-item
-// Cornell box 19.4 / 17.7 (4.30), one with 104 lights 9.6 / 8.6 (4.45).
+// Measured at 1080p, wide against two-child, Grays/s (ratio of the estimates): 487-sphere field 21.5 /
+// 25.9 (2.52); 200 / 500 / 1 000 / 2 000 / 5 000 / 20 000 items in a slab 48.8 / 50.8 (2.65), 40.4 / 39.7
+// (2.74), 32.6 / 33.1 (2.83), 27.7 / 26.3 (2.86), 21.2 / 19.3 (2.94), 12.8 / 11.8 (2.99) (tools/tree_sweep.sh);
+// with earlier kernels 100 000 items 6.42 / 5.93 (3.04), a 12-item Cornell box 19.4 / 17.7 (4.30), one
+// with 104 lights 9.6 / 8.6 (4.45).
 // RTX_WIDE_MIN_RATIO and RTX_WIDE_MIN_ITEMS (scenes with fewer tree items walk the two-child tree)
 // override, for measurements and tests; RTX_TREE_STATS prints the estimates.
 constexpr double kWideMinVisitRatio = 2.7;
@@ -740,7 +741,8 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     // the kernels address these tables per lane with 32-bit byte offsets
     if (scan_info.size() * sizeof(rtxd::ScanHit) >= (1ull << 32) || fast_items.size() * sizeof(rtxd::BvhFastItem) >= (1ull << 32) ||
         tree.wide.size() * sizeof(rtxd::WideNode) >= (1ull << 32) || nodes.size() * sizeof(rtxd::BvhNode) >= (1ull << 32) ||
-        lights.size() * sizeof(rtxd::Light) >= (1ull << 32))
+        lights.size() * sizeof(rtxd::Light) >= (1ull << 32) || fast_maps.size() * sizeof(rtxd::BvhMap) >= (1ull << 32) ||
+        prims_padded.size() * sizeof(rtxd::Prim) >= (1ull << 32))
         return fail(RTX_ERR_TOO_LARGE, "a scene table exceeds 4 GiB");
     RTX_HIP(ctx->prims.upload(prims_padded));
     RTX_HIP(ctx->prim_info.upload(info));
