@@ -804,6 +804,8 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     v.light_bvh = light_bvh.empty() ? nullptr : ctx->light_bvh.ptr;
     v.n_light_bvh = (uint32_t)light_bvh.size();
     v.light_bvh_pad_ = 0;
+    v.n_lights_f = (float)s->n_lights;
+    v.inv_n_lights = s->n_lights ? 1.0f / (float)s->n_lights : 0.0f;
     std::memcpy(v.cam_origin, s->cam_origin, sizeof v.cam_origin);
     std::memcpy(v.cam_ll, s->cam_ll, sizeof v.cam_ll);
     std::memcpy(v.cam_u, s->cam_u, sizeof v.cam_u);

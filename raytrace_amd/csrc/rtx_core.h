@@ -1037,7 +1037,11 @@ RTX_DEV V3 sample_direction(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
         uint32_t index = 0;
         if (kListLit || sc.light_is_list) {
             float r = rng_nextf(&rng);
+#if RTX_DET
             index = min((uint32_t)(r * (float)sc.n_lights), sc.n_lights - 1u);
+#else
+            index = min((uint32_t)(r * sc.n_lights_f), sc.n_lights - 1u);
+#endif
         }
         E = at32(sc.lights, index);  // per-lane
         kind = E.kind;
@@ -1147,7 +1151,7 @@ RTX_DEV float light_pdf_fast(const SceneView& sc, V3 o, V3 v, float len2, float 
     } else {
         for (uint32_t k = 0; k < sc.n_lights; ++k) sum += light_pdf_one_fast(load_uniform(sc.lights, k), o, v, len2, inv_len);
     }
-    return sum * frcp((float)sc.n_lights);
+    return sum * sc.inv_n_lights;
 }
 #endif
 

@@ -249,6 +249,10 @@ struct SceneView {
     const LightBvhNode* light_bvh;  // null: light_pdf_tree visits every leaf
     uint32_t n_light_bvh;
     uint32_t light_bvh_pad_;
+    // n_lights as a float and its reciprocal (fast mode): wave-uniform operands from the kernel's
+    // arguments, where the conversion and the reciprocal worked out by the kernel were kept in two
+    // vector registers across its loop - and spilled
+    float n_lights_f, inv_n_lights;
 };
 
 struct TraceArgs {
