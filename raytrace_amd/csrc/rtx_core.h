@@ -1553,6 +1553,7 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
     struct alignas(16) WaveLds {
 #if !RTX_DET
         uint4 slot[64];
+        float4 pixel_u, pixel_v;  // one pixel's step along the two image axes (a broadcast read per new item)
 #endif
         float acc[3][64];
     };
@@ -1585,9 +1586,11 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
     // integer multiply-add and two conversions.
     const float inv_nx = frcp((float)a.width), inv_ny = frcp((float)a.height);
     // one pixel's step along the two image axes (wave-uniform: back into scalar registers)
-    const auto uniform = [](float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
-    const V3 pixel_u = v3(uniform(sc.cam_u[0] * inv_nx), uniform(sc.cam_u[1] * inv_nx), uniform(sc.cam_u[2] * inv_nx));
-    const V3 pixel_v = v3(uniform(sc.cam_v[0] * inv_ny), uniform(sc.cam_v[1] * inv_ny), uniform(sc.cam_v[2] * inv_ny));
+    // one pixel's step along the two image axes: kept in LDS, not in six scalar registers for the whole loop
+    if (lane == 0u) {
+        s_wave[wave].pixel_u = make_float4(sc.cam_u[0] * inv_nx, sc.cam_u[1] * inv_nx, sc.cam_u[2] * inv_nx, 0.0f);
+        s_wave[wave].pixel_v = make_float4(sc.cam_v[0] * inv_ny, sc.cam_v[1] * inv_ny, sc.cam_v[2] * inv_ny, 0.0f);
+    }
     {
         const uint32_t sx = lane & (tile_w - 1u), sy = lane >> twl;
         const uint32_t i = x0 + sx, j = y0 + sy;
@@ -1646,8 +1649,9 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
                     // (the origin from here on as the vector registers just written, not as three scalar
                     // operands again: an instruction with a scalar operand issues at half rate)
                     asm("" : "+v"(ps.o.x), "+v"(ps.o.y), "+v"(ps.o.z));
+                    const float4 pu = s_wave[wave].pixel_u, pv = s_wave[wave].pixel_v;
                     ps.d = (v3(__uint_as_float(slot_info.y), __uint_as_float(slot_info.z), __uint_as_float(slot_info.w)) +
-                            pixel_u * du) + pixel_v * dv;
+                            v3(pu.x, pu.y, pu.z) * du) + v3(pv.x, pv.y, pv.z) * dv;
                     // The reference forms the direction as (lower-left + ...) - origin (Camera.h:24-26),
                     // i.e. it rounds the point on the image plane in WORLD coordinates before it
                     // subtracts the origin, which puts the directions on a grid of one ulp of those
