@@ -8,8 +8,8 @@ the whole frame (default workload: the reference Cornell box at 1920x1080,
 512 spp per GPU per step — with 8 GPUs one step is the 4096-spp frame of the
 headline configuration, with one GPU it is one GPU's share of it), followed for
 N > 1 by the RCCL sum-reduce of the fp32 accumulators to rank 0 and, on rank 0,
-the resolve to 8 bits; reduce and resolve of a step run on a second stream while the next
-step renders (two accumulators alternate).  Ranks render disjoint absolute sample ranges (weak
+the resolve to 8 bits; for N > 1 reduce and resolve of a step run on a second stream while the
+next step renders (two accumulators alternate), a single GPU runs them in line.  Ranks render disjoint absolute sample ranges (weak
 scaling: per-GPU work is fixed); the random stream is keyed by the absolute
 sample index, so the image does not depend on N beyond fp32 summation order.
 
@@ -371,10 +371,17 @@ def main() -> int:
     if engine is None:
         # the 8-bit image of every step lands in page-locked memory: the copy back is then a DMA transfer
         # and not a series of copy kernels that share the CUs with the next step's rendering
-        image_host = torch.empty((h, w, 3), dtype=torch.uint8).pin_memory().numpy() if rank == 0 else None
+        image_pinned = torch.empty((h, w, 3), dtype=torch.uint8).pin_memory() if rank == 0 else None
+        image_host = image_pinned.numpy() if rank == 0 else None
+        image_dev = torch.empty((h, w, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
+        copy_stream = torch.cuda.Stream(dev) if rank == 0 else None  # the copy back of a step's image
+        copied = [None]
         render_stream = torch.cuda.current_stream(dev)
-        # reduce + resolve of step k while step k+1 renders
-        side_stream = render_stream if args.serial else torch.cuda.Stream(dev)
+        # reduce + resolve of step k while step k+1 renders.  With one GPU there is no reduce to hide: the
+        # frame addition and the resolve take 25 us behind the trace kernel on its own stream, but 1 ms
+        # each - and 1 % of the next step's rendering - when they share the GPU with it from a second stream
+        # (measured: 103.3 against 102.2 Grays/s whole job), so a single rank runs them in line.
+        side_stream = render_stream if (args.serial or world == 1) else torch.cuda.Stream(dev)
     else:
         render_stream = side_stream = None
     ev = {}
@@ -409,8 +416,17 @@ def main() -> int:
             frame_accum.add_(buf)
             if engine is not None:
                 return api.resolve_host(frame_accum.numpy(), total_spp_done)
-            return ctx.resolve_device(w, h, total_spp_done, frame_accum.data_ptr(), side_stream.cuda_stream,
-                                      out=image_host)
+            # the 8-bit image is made on the GPU behind the frame addition; its copy into page-locked memory
+            # runs on a stream of its own while the next step renders (the image buffer is not written
+            # again before that copy has finished)
+            if copied[0] is not None:
+                side_stream.wait_event(copied[0])
+            ctx.resolve_to_device(w, h, total_spp_done, frame_accum.data_ptr(), image_dev.data_ptr(), side_stream.cuda_stream)
+            copy_stream.wait_event(side_stream.record_event())
+            with torch.cuda.stream(copy_stream):
+                image_pinned.copy_(image_dev, non_blocking=True)
+                copied[0] = copy_stream.record_event()
+            return image_host  # complete once the device has been synchronised
         return None
 
     run_pipelined_steps(range(args.warmup), render, combine, step_accum, render_stream, side_stream)
@@ -472,8 +488,9 @@ def main() -> int:
                 "max_depth": 50,
                 "mode": args.mode,
                 "accel": "bvh" if bvh else "linear",
-                "parallelism": f"spp-split x{world}, reduce(sum) of fp32 accumulators to rank 0 per step, "
-                               "overlapped with the next step's rendering",
+                "parallelism": (f"spp-split x{world}, reduce(sum) of fp32 accumulators to rank 0 per step, "
+                                "overlapped with the next step's rendering") if world > 1 else
+                               "one GPU: frame addition and resolve of a step in line behind its trace kernel",
             },
             "spp_per_s": spp * world * args.steps / elapsed,
             "msamples_per_s": samples / elapsed / 1e6,

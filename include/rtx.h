@@ -277,6 +277,15 @@ int rtx_hit(RtxContext* ctx, uint32_t n, const float* origins, const float* dire
 int rtx_resolve_device(RtxContext* ctx, uint32_t width, uint32_t height, uint32_t ns,
                        const float* d_accum_rgb, uint8_t* rgb8, void* hip_stream);
 
+/*
+ * The same epilogue (Scene.cpp:150-151, Image.h:30-39) with the 8-bit image left on the GPU:
+ * `d_rgb8` is a DEVICE buffer of width*height*3 bytes.  Only enqueues the kernel on
+ * `hip_stream` and returns: for callers that display or encode the frame on the GPU, or that copy
+ * it back on a stream of their own while the next frame renders.
+ */
+int rtx_resolve_to_device(RtxContext* ctx, uint32_t width, uint32_t height, uint32_t ns,
+                          const float* d_accum_rgb, uint8_t* d_rgb8, void* hip_stream);
+
 /* Introspection for tests and reports. */
 typedef struct RtxSceneInfo {
     uint32_t n_prims;

@@ -97,7 +97,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("prim", "<i4"), ("t", "<f4"),
 RTX_SYMBOLS = (
     "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_device_count", "rtx_upload_scene",
     "rtx_render", "rtx_render_device", "rtx_render_samples", "rtx_hit", "rtx_resolve_device",
-    "rtx_scene_info", "rtx_render_multi", "rtx_render_noalloc",
+    "rtx_scene_info", "rtx_render_multi", "rtx_render_noalloc", "rtx_resolve_to_device",
 )
 RTX_NOALLOC_MAX_PIXELS = 1 << 21
 RTXH_SYMBOLS = (
@@ -170,6 +170,8 @@ def load_librtx() -> C.CDLL:
         lib.rtx_resolve_device.argtypes = [ctxp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                            C.c_void_p, C.c_void_p]
         lib.rtx_resolve_device.restype = C.c_int
+        lib.rtx_resolve_to_device.argtypes = [ctxp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rtx_resolve_to_device.restype = C.c_int
         lib.rtx_scene_info.argtypes = [ctxp, C.POINTER(RtxSceneInfo)]
         lib.rtx_scene_info.restype = C.c_int
         _librtx = lib
@@ -367,6 +369,12 @@ class Context:
         self._check(self._lib.rtx_resolve_device(self._ctx, width, height, ns, C.c_void_p(d_accum),
                                                  out.ctypes.data, C.c_void_p(stream) if stream else None))
         return out
+
+
+    def resolve_to_device(self, width: int, height: int, ns: int, d_accum: int, d_rgb8: int, stream: int = 0) -> None:
+        """rtx_resolve_to_device: the 8-bit image into the device buffer at `d_rgb8`; enqueues and returns."""
+        self._check(self._lib.rtx_resolve_to_device(self._ctx, width, height, ns, C.c_void_p(d_accum), C.c_void_p(d_rgb8),
+                                                    C.c_void_p(stream) if stream else None))
 
 
 def render_multi(contexts, params: RtxParams, accum: Optional[np.ndarray] = None) -> Tuple[np.ndarray, int]:

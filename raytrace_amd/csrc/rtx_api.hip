@@ -1066,4 +1066,15 @@ int rtx_resolve_device(RtxContext* ctx, uint32_t width, uint32_t height, uint32_
     return RTX_OK;
 }
 
+int rtx_resolve_to_device(RtxContext* ctx, uint32_t width, uint32_t height, uint32_t ns,
+                          const float* d_accum_rgb, uint8_t* d_rgb8, void* hip_stream) {
+    if (!ctx) return fail(RTX_ERR_INVALID_ARGUMENT, "context is null");
+    if (!d_accum_rgb || !d_rgb8) return fail(RTX_ERR_INVALID_ARGUMENT, "null buffer");
+    if (width == 0 || height == 0 || ns == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "empty image or ns == 0");
+    if ((uint64_t)width * height > (1ull << 30)) return fail(RTX_ERR_TOO_LARGE, "more than 2^30 pixels");
+    RTX_HIP(hipSetDevice(ctx->device));
+    RTX_HIP(rtx_post::launch_resolve(d_accum_rgb, d_rgb8, width * height, ns, static_cast<hipStream_t>(hip_stream)));
+    return RTX_OK;
+}
+
 }  // extern "C"

@@ -455,6 +455,12 @@ def test_device_resolve_matches_host_filter_chain(gpu_ctx):
     sums = (rng.random((64, 96, 3)) * 700).astype(np.float32)
     for ns in (3, 7, 512, 4096):
         assert np.array_equal(device_bytes(sums, ns), api.resolve_host(sums, ns))
+    # the entry point that leaves the image on the GPU gives the same bytes
+    t = torch.from_numpy(sums).to("cuda:0")
+    d_img = torch.zeros((64, 96, 3), dtype=torch.uint8, device="cuda:0")
+    gpu_ctx.resolve_to_device(96, 64, 7, t.data_ptr(), d_img.data_ptr(), s.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_img.cpu().numpy(), api.resolve_host(sums, 7))
 
     w, h, spp = 1920, 1080, 4
     scene = api.HostScene("cornell", w, h)
