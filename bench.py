@@ -179,8 +179,12 @@ def parse_args(argv=None):
                     help="one process drives all --gpus devices through rtx_render_multi (the C ABI's own split: "
                          "peer copies to device 0, ordered adds) instead of one process per GPU with RCCL")
     ap.add_argument("--share-device", action="store_true",
-                    help="with --single-process: put every context on device 0 when fewer than --gpus devices "
-                         "are visible (functional rehearsal on a one-GPU box; the number is not a scaling result)")
+                    help="put the ranks (or, with --single-process, the contexts) on the devices that exist, several "
+                         "to a device, when fewer than --gpus are visible: a functional rehearsal of the N > 1 code on "
+                         "a one-GPU box, with --backend gloo (RCCL refuses two ranks on one device); the number is "
+                         "not a scaling result")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the GPU ranks (nccl = RCCL; gloo only for --share-device rehearsals)")
     ap.add_argument("--engine", default="",
                     help="test hook: dotted module name providing make_engine(scene, width, height, mode) -> object "
                          "with render(begin, count) -> (fp32 SUM frame as a CPU torch tensor, rays); the ranks then "
@@ -203,7 +207,7 @@ def launch_ranks(args) -> int:
         import torch  # device_count() does not initialise the GPU
 
         visible = torch.cuda.device_count()
-        if visible < n:
+        if visible < n and not (args.share_device and visible >= 1):
             print(f"bench.py: --gpus {n} but only {visible} GPU(s) visible", file=sys.stderr)
             return 2
     with socket.socket() as sock:
@@ -333,6 +337,10 @@ def main() -> int:
     from raytrace_amd import api
     from raytrace_amd.distributed import run_pipelined_steps, step_sample_range
 
+    def trace(msg):  # RTX_BENCH_TRACE=1: where a rank is, on stderr (a run that hangs says where)
+        if os.environ.get("RTX_BENCH_TRACE"):
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
     scene_name, w, h, spp_default = WORKLOADS[args.workload]
     w, h = args.width or w, args.height or h
     spp = args.spp_per_step or spp_default
@@ -350,12 +358,18 @@ def main() -> int:
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
+        if args.share_device:
+            local_rank %= torch.cuda.device_count()
         if local_rank >= torch.cuda.device_count():
             raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         if world > 1:
-            dist.init_process_group("nccl", device_id=dev)
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+        trace("process group up")
         ctx = api.Context(local_rank)
         scene = api.HostScene(scene_name, w, h)
         ctx.upload(scene, api.RTX_ACCEL_AUTO)
@@ -410,7 +424,9 @@ def main() -> int:
     def combine(k: int, buf):
         nonlocal total_spp_done
         if world > 1:
+            trace(f"reduce of step {k}")
             dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
+            trace(f"reduce of step {k} returned")
         total_spp_done += spp * world
         if rank == 0:
             frame_accum.add_(buf)
@@ -429,8 +445,10 @@ def main() -> int:
             return image_host  # complete once the device has been synchronised
         return None
 
+    trace("scene uploaded, warm-up")
     run_pipelined_steps(range(args.warmup), render, combine, step_accum, render_stream, side_stream)
     sync()
+    trace("warm-up done")
     rays.zero_()
     frame_accum.zero_()  # the reported frame holds the timed steps' samples only
     total_spp_done = 0
@@ -442,6 +460,7 @@ def main() -> int:
     images = run_pipelined_steps(range(args.warmup, args.warmup + args.steps), render, combine, step_accum,
                                  render_stream, side_stream)
     sync()
+    trace("timed steps done")
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
