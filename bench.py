@@ -172,8 +172,8 @@ def parse_args(argv=None):
     ap.add_argument("--mode", default="fast", choices=["fast", "deterministic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true",
-                    help="reduce / resolve on the render stream (no overlap): per-kernel counters then see the "
-                         "trace kernel alone")
+                    help="reduce / resolve on the render stream and a device synchronisation after every step: "
+                         "per-kernel counters then see the trace kernel alone")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--single-process", action="store_true",
                     help="one process drives all --gpus devices through rtx_render_multi (the C ABI's own split: "
@@ -442,6 +442,8 @@ def main() -> int:
             with torch.cuda.stream(copy_stream):
                 image_pinned.copy_(image_dev, non_blocking=True)
                 copied[0] = copy_stream.record_event()
+            if args.serial:  # counter runs: the GPU drains between steps, so that what the frame addition and the
+                sync()       # resolve left dirty in the L2 is not written back inside the next trace kernel's window
             return image_host  # complete once the device has been synchronised
         return None
 
