@@ -172,8 +172,8 @@ def parse_args(argv=None):
     ap.add_argument("--mode", default="fast", choices=["fast", "deterministic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true",
-                    help="reduce / resolve on the render stream and a device synchronisation after every step: "
-                         "per-kernel counters then see the trace kernel alone")
+                    help="reduce / resolve on the render stream and a synchronous copy back of the image after every "
+                         "step: per-kernel counters then see the trace kernel alone")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--single-process", action="store_true",
                     help="one process drives all --gpus devices through rtx_render_multi (the C ABI's own split: "
@@ -435,6 +435,12 @@ def main() -> int:
             # the 8-bit image is made on the GPU behind the frame addition; its copy into page-locked memory
             # runs on a stream of its own while the next step renders (the image buffer is not written
             # again before that copy has finished)
+            if args.serial:
+                # counter runs: resolve and copy back in one synchronous call.  The copy back makes the runtime
+                # write the L2 back first, so that what the frame addition and the resolve left dirty there is
+                # not written back inside the next trace kernel's window (and counted as its traffic)
+                return ctx.resolve_device(w, h, total_spp_done, frame_accum.data_ptr(), side_stream.cuda_stream,
+                                          out=image_host)
             if copied[0] is not None:
                 side_stream.wait_event(copied[0])
             ctx.resolve_to_device(w, h, total_spp_done, frame_accum.data_ptr(), image_dev.data_ptr(), side_stream.cuda_stream)
@@ -442,8 +448,6 @@ def main() -> int:
             with torch.cuda.stream(copy_stream):
                 image_pinned.copy_(image_dev, non_blocking=True)
                 copied[0] = copy_stream.record_event()
-            if args.serial:  # counter runs: the GPU drains between steps, so that what the frame addition and the
-                sync()       # resolve left dirty in the L2 is not written back inside the next trace kernel's window
             return image_host  # complete once the device has been synchronised
         return None
 
