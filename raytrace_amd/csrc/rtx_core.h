@@ -1887,7 +1887,7 @@ RTX_DEV uint32_t exchange_slots(uint32_t x, uint32_t swaps) {
 // sc.bvh_fast).  The wide tree's chain of dependent fetches is a third as long, but a step down
 // it costs about three times the instructions: it wins on large trees, the two-child tree on
 // small ones whose nodes all stay in the caches (see launch_trace).
-template <bool kLightTree, bool kSamples, bool kWide>
+template <bool kLightTree, bool kSamples, bool kWide, bool kListLit = false>
 __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel(const TraceArgs a) {
 #ifdef RTX_BVH_STATS
     uint32_t stat[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // wave-uniform
@@ -1970,11 +1970,11 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 if (best != kNone) {  // the winner's record lives inside this branch only
                     HitRec rec;
                     finish_scan_hit<true>(sc, best, closest, ps.o, ps.d, false, rec);
-                    ended = shade<kLightTree>(sc, a.max_depth, true, rec, ps, L);
+                    ended = shade<kLightTree, kListLit>(sc, a.max_depth, true, rec, ps, L);
                 } else {
                     HitRec none;
                     none.bits = 0u;
-                    ended = shade<kLightTree>(sc, a.max_depth, false, none, ps, L);
+                    ended = shade<kLightTree, kListLit>(sc, a.max_depth, false, none, ps, L);
                 }
                 if (ended) {
                     const uint32_t slot = item & pix_mask;
