@@ -726,6 +726,20 @@ RTX_DEV uint32_t pop_ref(uint32_t (*stack)[kCols], uint32_t& sp, uint32_t tid) {
 // One fast-mode leaf record against this lane's ray (inv / noi: the capped reciprocal
 // direction and -o * inv of the traversal).  Ties between equal distances are not ordered:
 // fast mode only has to be statistically equal.
+// A lane's leaf record as two 16-byte loads issued together: read field by field, the type
+// comes first and the fields of that type a memory round trip later.
+RTX_DEV BvhFastItem load_fast_item(const BvhFastItem* base, uint32_t i) {
+    static_assert(sizeof(BvhFastItem) == 32, "two uint4");
+    const uint4* q = reinterpret_cast<const uint4*>(&at32(base, i));
+    uint4 a = q[0], b = q[1];
+    asm("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+    BvhFastItem I;
+    I.f[0] = __uint_as_float(a.x); I.f[1] = __uint_as_float(a.y); I.f[2] = __uint_as_float(a.z);
+    I.f[3] = __uint_as_float(a.w); I.f[4] = __uint_as_float(b.x);
+    I.slot = b.y; I.type_count = b.z; I.map = b.w;
+    return I;
+}
+
 RTX_DEV void fast_leaf_item(const SceneView& sc, const BvhFastItem& I, V3 o, V3 d, V3 inv, V3 noi, float t0,
                             float& closest, uint32_t& best) {
     const uint32_t type = I.type_count & 0xffu;
@@ -2109,12 +2123,13 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     // is read from the node again: per ray there are ten node steps to one leaf
                     const uint32_t k = (uint32_t)__ffs((int)ig_bits) - 1u;
                     ig_bits &= ig_bits - 1u;
-                    const uint4 n1 = reinterpret_cast<const uint4*>(&at32(sc.bvh_wide, ig_node))[1];
+                    uint4 n1 = reinterpret_cast<const uint4*>(&at32(sc.bvh_wide, ig_node))[1];
+                    asm("" : "+v"(n1.y), "+v"(n1.z), "+v"(n1.w));  // one load, not the meta word and then item_base
                     const uint32_t meta = ((k < 4u ? n1.z : n1.w) >> (8u * (k & 3u))) & 0xffu;
                     uint32_t first = n1.y + (meta & 31u);
                     // (an empty slot - count 0 - is never met: its box is inverted; the loop still ends on it)
                     for (uint32_t left = (uint32_t)__popc(meta >> 5); left != 0u; --left, ++first)
-                        fast_leaf_item(sc, at32(sc.wide_items, first), ps.o, ps.d, inv, noi, kTMin, closest, best);
+                        fast_leaf_item(sc, load_fast_item(sc.wide_items, first), ps.o, ps.d, inv, noi, kTMin, closest, best);
                     if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
                 }
             } else {
@@ -2142,7 +2157,7 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 if (leaves_now && at_leaf) {
                     const uint32_t first = ref & kBvhLeafFirst, count = (ref >> kBvhLeafCountShift) & 15u;
                     for (uint32_t k = 0; k < count; ++k)
-                        fast_leaf_item(sc, at32(sc.bvh_fast, first + k), ps.o, ps.d, inv, noi, kTMin, closest, best);
+                        fast_leaf_item(sc, load_fast_item(sc.bvh_fast, first + k), ps.o, ps.d, inv, noi, kTMin, closest, best);
                     if (sp != 0u) {
                         --sp;
                         ref = s_stack2[sp][tid];
