@@ -727,10 +727,11 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
                          items.size(), tree.nodes.size(), tree.depth, tree.visits_two_child, tree.wide.size(), tree.visits_wide,
                          tree.visits_wide > 0.0 ? tree.visits_two_child / tree.visits_wide : 0.0);
         // the eight-wide tree of the fast trace kernel reads the leaf records in its own order; a
-        // tree deeper than that kernel's stack, or one that saves too few steps (see
+        // tree deeper than that kernel's stack, one of 2^24 records or more, or one that saves too few steps (see
         // kWideMinVisitRatio), is rendered through the two-child tree instead
         const bool wide_pays = tree.visits_wide > 0.0 && tree.visits_two_child >= wide_min_ratio() * tree.visits_wide;
-        if (tree.wide_depth <= rtxd::kWideStackEntries && items.size() >= wide_min_items() && wide_pays) {
+        if (tree.wide_depth <= rtxd::kWideStackEntries && items.size() >= wide_min_items() && wide_pays &&
+            tree.wide_order.size() <= rtxd::kWideItemBase) {
             wide_items.reserve(tree.wide_order.size());
             for (uint32_t k : tree.wide_order) wide_items.push_back(fast_items[k]);
         } else {

@@ -162,15 +162,9 @@ double wide_leaf_cost() {
     const char* e = std::getenv("RTX_WIDE_LEAF_COST");
     return e ? std::atof(e) : 0.3;
 }
-uint32_t wide_leaf_items() {
-    const char* e = std::getenv("RTX_WIDE_LEAF_ITEMS");
-    const int v = e ? std::atoi(e) : 1;
-    return (uint32_t)std::min(std::max(v, 1), 3);
-}
-
 void wide_costs(const std::vector<TmpNode>& nodes, std::vector<WideCost>& cost) {
     const double kLeafCost = wide_leaf_cost();
-    const uint32_t kMaxLeaf = wide_leaf_items();
+    constexpr uint32_t kMaxLeaf = 1;  // one record per leaf slot: the walk finds it by counting leaf slots
     cost.assign(nodes.size(), WideCost{});
     // children lie behind their parent in `nodes`: a backward pass is a post-order pass
     for (size_t n = nodes.size(); n-- > 0;) {
@@ -298,7 +292,8 @@ void build_wide(const std::vector<TmpNode>& nodes, Tree& out) {
             W.e[a] = (uint8_t)(e + 127);
             step[a] = std::ldexp(1.0, e);
         }
-        W.item_base = (uint32_t)out.wide_order.size();
+        const uint32_t item_base = (uint32_t)out.wide_order.size();
+        uint32_t leaf_slots = 0;
         uint32_t n_inner = 0;
         for (int sidx = 0; sidx < 8; ++sidx) {
             for (int a = 0; a < 3; ++a) {  // an empty slot: an inverted box no ray meets
@@ -319,12 +314,13 @@ void build_wide(const std::vector<TmpNode>& nodes, Tree& out) {
                 W.meta[sidx] = (uint8_t)(0x20u | (24u + (uint32_t)sidx));
                 ++n_inner;
             } else {
-                const uint32_t offset = (uint32_t)out.wide_order.size() - W.item_base;  // < 24: at most 8 x 3 items
-                const uint32_t unary = (1u << K.n_items) - 1u;                         // n_items <= 3
-                W.meta[sidx] = (uint8_t)((unary << 5) | offset);
-                for (uint32_t k = 0; k < K.n_items; ++k) out.wide_order.push_back(K.first + k);
+                const uint32_t offset = (uint32_t)out.wide_order.size() - item_base;  // = leaf slots below this one
+                W.meta[sidx] = (uint8_t)(0x20u | offset);
+                leaf_slots |= 1u << sidx;
+                out.wide_order.push_back(K.first);  // K.n_items == 1
             }
         }
+        W.items = (item_base & rtxd::kWideItemBase) | (leaf_slots << 24);
         W.child_base = (uint32_t)out.wide.size();
         out.wide.resize(out.wide.size() + n_inner);
         uint32_t rel = 0;
@@ -502,7 +498,7 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
         err = "too many BVH items";
         return false;
     }
-    static_assert(kLeafItems <= 3, "a wide node's meta byte counts a leaf's items in unary, three bits");
+    static_assert(kLeafItems == 1, "a wide node's leaf slot holds one record");
     build_wide(nodes, out);
     {   // expected node visits of a ray through the root box, by the surface-area measure
         const double root = nodes[0].box.area();

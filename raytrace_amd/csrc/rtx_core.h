@@ -1943,7 +1943,7 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
     // node's imask); an item group the leaf slots still to test: the node and their slot bits.
     // `order`: c = 7 - octant(ray) in its top byte (slots are visited in descending order of
     // slot ^ c), the exchange masks of c below (exchange_slots).
-    uint32_t ng_base = 0u, ng_bits = 0u, ig_node = 0u, ig_bits = 0u, order = 0u;
+    uint32_t ng_base = 0u, ng_bits = 0u, ig_items = 0u, ig_bits = 0u, order = 0u;
     uint32_t sp = 0, best = kNone;
     float closest = kFltMax;
     V3 inv = v3(0.0f, 0.0f, 0.0f), noi = inv;
@@ -2107,29 +2107,24 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     }
                     const uint4* p = reinterpret_cast<const uint4*>(&at32(sc.bvh_wide, node));
                     const uint4 n0 = p[0], n2 = p[2], n3 = p[3], n4 = p[4];
-                    const uint32_t child_base = reinterpret_cast<const uint32_t*>(p)[4];
+                    const uint2 bases = reinterpret_cast<const uint2*>(p)[2];  // child_base, items word
                     const uint32_t hits = wide_node_hits(n0, n2, n3, n4, inv, noi, kTMin, closest);
                     RTX_STAT(11, (uint32_t)__popcll(rtx_ballot(hits == 0u)));  // [11] node steps that met no child
                     RTX_STAT(10, (uint32_t)__popcll(rtx_ballot(hits == 0u && best != kNone)));  // [10] ... with a hit in hand
                     const uint32_t imask = n0.w >> 24;
-                    ng_base = child_base;
+                    ng_base = bases.x;
                     ng_bits = (exchange_slots(hits & imask, order) << 24) | imask;
-                    ig_node = node;
+                    ig_items = bases.y;
                     ig_bits = hits & ~imask;
                     if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
                 }
                 if (leaves_now && at_leaf) {
-                    // the slot's meta byte (unary item count << 5 | first item's offset from item_base)
-                    // is read from the node again: per ray there are ten node steps to one leaf
+                    // slot k's record: the node's first one + the leaf slots below k (the items word's top
+                    // byte); nothing of the node is read again
                     const uint32_t k = (uint32_t)__ffs((int)ig_bits) - 1u;
                     ig_bits &= ig_bits - 1u;
-                    uint4 n1 = reinterpret_cast<const uint4*>(&at32(sc.bvh_wide, ig_node))[1];
-                    asm("" : "+v"(n1.y), "+v"(n1.z), "+v"(n1.w));  // one load, not the meta word and then item_base
-                    const uint32_t meta = ((k < 4u ? n1.z : n1.w) >> (8u * (k & 3u))) & 0xffu;
-                    uint32_t first = n1.y + (meta & 31u);
-                    // (an empty slot - count 0 - is never met: its box is inverted; the loop still ends on it)
-                    for (uint32_t left = (uint32_t)__popc(meta >> 5); left != 0u; --left, ++first)
-                        fast_leaf_item(sc, load_fast_item(sc.wide_items, first), ps.o, ps.d, inv, noi, kTMin, closest, best);
+                    const uint32_t first = (ig_items & kWideItemBase) + (uint32_t)__popc(__builtin_amdgcn_ubfe(ig_items, 24u, k));
+                    fast_leaf_item(sc, load_fast_item(sc.wide_items, first), ps.o, ps.d, inv, noi, kTMin, closest, best);
                     if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
                 }
             } else {

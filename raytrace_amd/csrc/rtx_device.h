@@ -168,9 +168,11 @@ constexpr uint32_t kBvhLeafCountShift = 27u;
 // node decides eight subtrees per fetch: 80 bytes = five 16-byte loads.  The children's boxes are
 // 8-bit coordinates on the node's own grid p + q * 2^e (per axis; rounded outwards), decoded
 // inside the slab test's fused multiply-adds.  Children that are inner nodes lie consecutively
-// from `child_base` in slot order; children that are leaves own consecutive records of
-// `wide_items` from `item_base`.  Per slot, `meta` is 0 (empty), 0x20 | (24 + slot) for an inner
-// node, or (count in unary: 1, 3, 7) << 5 | offset of its first item from item_base.  Slots are
+// from `child_base` in slot order; children that are leaves hold one record of `wide_items`
+// each, consecutive in slot order from `items & kWideItemBase`, and bits 24..31 of `items` say
+// which slots are leaves: slot k's record is the base + the leaf slots below k, known without
+// another look at the node.  `meta` (0 empty, 0x20 | (24 + slot) inner node, 0x20 | offset of
+// the record from the base for a leaf) restates that per slot for host-side checks.  Slots are
 // assigned so that slot bit a set means "towards +axis a" within the node: a ray visits the
 // slots in ascending order of slot ^ octant(ray), which is roughly front to back and needs no
 // sorting.  (Layout after Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal on GPUs
@@ -180,7 +182,7 @@ struct alignas(16) WideNode {
     uint8_t e[3];       // biased fp32 exponent of the grid step per axis
     uint8_t imask;      // bit s: slot s holds an inner node
     uint32_t child_base;
-    uint32_t item_base;
+    uint32_t items;     // first leaf record | leaf slots << 24
     uint8_t meta[8];
     uint8_t qlo[3][8];  // [axis][slot]
     uint8_t qhi[3][8];
@@ -189,6 +191,7 @@ static_assert(sizeof(WideNode) == 80, "five 16-byte loads");
 // Entries of the wide traversal's per-lane stack (8 bytes each): one per level that still has
 // unvisited children.  Deeper trees are rendered through the two-child tree instead.
 constexpr int kWideStackEntries = 12;
+constexpr uint32_t kWideItemBase = 0x00ffffffu;  // a wide tree holds fewer than 2^24 leaf records
 
 // Fast-mode leaf record, one per BVH item in leaf order, so that a leaf costs one 32-byte
 // fetch instead of the chain item -> steps -> primitive:

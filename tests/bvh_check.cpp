@@ -259,6 +259,7 @@ int main(int argc, char** argv) {
             for (int sidx = 0; sidx < 8; ++sidx) {
                 const uint32_t meta = W.meta[sidx];
                 const bool inner = (W.imask >> sidx) & 1u;
+                if ((inner || meta == 0u) && ((W.items >> (24 + sidx)) & 1u)) return fail("wide tree: items word marks a slot that is no leaf");
                 if (inner) {
                     if (meta != (0x20u | (24u + (uint32_t)sidx))) return fail("wide tree: inner slot meta");
                     const uint32_t c = W.child_base + rel++;
@@ -266,11 +267,16 @@ int main(int argc, char** argv) {
                     ++node_seen[c];
                 } else if (meta != 0u) {
                     const uint32_t unary = meta >> 5, offset = meta & 31u;
+                    // the device finds the record by counting the leaf slots below this one
+                    const uint32_t leaf_slots = W.items >> 24;
+                    if (!((leaf_slots >> sidx) & 1u)) return fail("wide tree: leaf slot missing from the items word");
+                    if (offset != (uint32_t)__builtin_popcount(leaf_slots & ((1u << sidx) - 1u)) || unary != 1u)
+                        return fail("wide tree: leaf record is not at its slot's rank");
                     const uint32_t count = unary == 1u ? 1u : (unary == 3u ? 2u : (unary == 7u ? 3u : 99u));
                     if (count == 99u || offset + count > 24u) return fail("wide tree: leaf slot meta");
                     for (uint32_t k = 0; k < count; ++k) {
-                        if (W.item_base + offset + k >= n_tree_items) return fail("wide tree: leaf item out of range");
-                        ++item_seen[W.item_base + offset + k];
+                        if ((W.items & rtxd::kWideItemBase) + offset + k >= n_tree_items) return fail("wide tree: leaf item out of range");
+                        ++item_seen[(W.items & rtxd::kWideItemBase) + offset + k];
                     }
                 }
             }
@@ -331,7 +337,7 @@ int main(int argc, char** argv) {
                 hitmask |= (meta >> 5) << index;
             }
             for (uint32_t b = 0; b < 24u; ++b)
-                if ((hitmask >> b) & 1u) reached[W.item_base + b] = 1;
+                if ((hitmask >> b) & 1u) reached[(W.items & rtxd::kWideItemBase) + b] = 1;
             ng.base = W.child_base;
             ng.bits = (hitmask & 0xff000000u) | W.imask;
         }
