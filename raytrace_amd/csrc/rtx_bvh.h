@@ -15,7 +15,7 @@
 namespace rtxbvh {
 
 // Maximum tree depth the traversal stack supports (see kBvhStack in rtx_core.h).
-constexpr int kMaxDepth = 22;
+constexpr int kMaxDepth = 21;
 static_assert(kMaxDepth + 1 <= rtxd::kBvhStackEntries, "the traversal stack must hold one deferred child per level");
 
 // What the builder hands back.

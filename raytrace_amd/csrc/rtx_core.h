@@ -1880,8 +1880,10 @@ RTX_DEV uint32_t exchange_slots(uint32_t x, uint32_t swaps) {
                                 // 13.01 / 13.01 / 12.83
 #endif
 // One wave per block: a block's LDS and wave slots are free as soon as ITS pool is spent (the
-// waves of a 256-thread block wait for the slowest of the four), and the per-lane stack is 6 KB
-// per wave, so LDS no longer bounds the occupancy.
+// waves of a 256-thread block wait for the slowest of the four).  Six waves per SIMD are 24
+// blocks per CU, which leaves 160 KB / 24 = 6 826 bytes of LDS for each: the per-lane stack is
+// 5.5 KB and the pixel sums 0.75 KB (with 6 KB of stack, 6 912 bytes in all, only 22 - 23 blocks
+// fitted: 5 - 7 % slower on the BVH scenes).
 #ifndef RTX_BVH_BLOCK
 #define RTX_BVH_BLOCK 64
 #endif
@@ -1908,9 +1910,10 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
 #endif
     __shared__ float s_acc[RTX_BVH_BLOCK / 64][3][64];
     // per lane: the node groups of the levels above that still have children to visit (wide
-    // tree), or the deferred children (two-child tree; the same 6 KB per wave either way)
+    // tree), or the deferred children (two-child tree; the same 5.5 KB per wave either way)
     __shared__ uint2 s_stack[kWideStackEntries][RTX_BVH_BLOCK];
     static_assert(sizeof(uint2) * kWideStackEntries == sizeof(uint32_t) * kBvhStack, "one LDS block, two views");
+    static_assert((sizeof(s_stack) + sizeof(s_acc)) * 4 * RTX_BVH_WAVES <= 160 * 1024, "LDS must not bound the occupancy");
     uint32_t (*s_stack2)[RTX_BVH_BLOCK] = reinterpret_cast<uint32_t (*)[RTX_BVH_BLOCK]>(&s_stack[0][0]);
     const SceneView& sc = a.scene;
     const uint32_t tid = threadIdx.x, lane = threadIdx.x & 63u;

@@ -157,8 +157,10 @@ struct alignas(32) BvhNode {
     uint32_t child0, child1;
 };
 // Entries of the traversal's per-lane stack: one deferred child per level, so a tree may be at
-// most kBvhStackEntries - 1 levels deep (the builder bounds it, the upload checks it).
-constexpr int kBvhStackEntries = 24;
+// most kBvhStackEntries - 1 levels deep (the builder bounds it, the upload checks it).  The fast
+// BVH trace kernel's occupancy hangs on this number and on kWideStackEntries: 256 bytes of LDS per
+// wave and entry, 5.5 KB per wave as they stand, and 6 KB would cost it two resident waves per CU.
+constexpr int kBvhStackEntries = 22;
 constexpr uint32_t kBvhLeaf = 0x80000000u;
 constexpr uint32_t kBvhLeafFirst = 0x07ffffffu;
 constexpr uint32_t kBvhLeafCountShift = 27u;
@@ -190,7 +192,7 @@ struct alignas(16) WideNode {
 static_assert(sizeof(WideNode) == 80, "five 16-byte loads");
 // Entries of the wide traversal's per-lane stack (8 bytes each): one per level that still has
 // unvisited children.  Deeper trees are rendered through the two-child tree instead.
-constexpr int kWideStackEntries = 12;
+constexpr int kWideStackEntries = 11;
 constexpr uint32_t kWideItemBase = 0x00ffffffu;  // a wide tree holds fewer than 2^24 leaf records
 
 // Fast-mode leaf record, one per BVH item in leaf order, so that a leaf costs one 32-byte
