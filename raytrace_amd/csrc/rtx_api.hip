@@ -372,14 +372,14 @@ void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rt
 // instructions of a step down the two-child tree, so it pays when it saves enough steps: by the
 // surface-area estimates of the builder (expected node visits of a ray through the root box), the
 // wide tree is used when the two-child tree needs at least kWideMinVisitRatio times its visits.
-// Measured at 1080p, wide against two-child, Grays/s (ratio of the estimates): 487-sphere field 21.5 /
-// 25.9 (2.52); 200 / 500 / 1 000 / 2 000 / 5 000 / 20 000 items in a slab 48.8 / 50.8 (2.65), 40.4 / 39.7
-// (2.74), 32.6 / 33.1 (2.83), 27.7 / 26.3 (2.86), 21.2 / 19.3 (2.94), 12.8 / 11.8 (2.99) (tools/tree_sweep.sh);
-// with earlier kernels 100 000 items 6.42 / 5.93 (3.04), a 12-item Cornell box 19.4 / 17.7 (4.30), one
+// Measured at 1080p, wide against two-child, Grays/s (ratio of the estimates): 487-sphere field 24.2 /
+// 27.9 (2.52); 200 / 500 / 1 000 / 2 000 / 5 000 / 20 000 items in a slab 52.0 / 53.5 (2.65), 42.6 / 42.9
+// (2.74), 34.0 / 36.2 (2.83), 28.8 / 29.2 (2.86), 21.9 / 21.7 (2.94), 13.9 / 13.6 (2.99) (tools/tree_sweep.sh);
+// 100 000 items 7.85 / 7.52 (3.04); with earlier kernels a 12-item Cornell box 19.4 / 17.7 (4.30), one
 // with 104 lights 9.6 / 8.6 (4.45).
 // RTX_WIDE_MIN_RATIO and RTX_WIDE_MIN_ITEMS (scenes with fewer tree items walk the two-child tree)
 // override, for measurements and tests; RTX_TREE_STATS prints the estimates.
-constexpr double kWideMinVisitRatio = 2.7;
+constexpr double kWideMinVisitRatio = 2.9;
 double wide_min_ratio() {
     const char* e = std::getenv("RTX_WIDE_MIN_RATIO");  // read at every upload: tests switch it
     return e ? std::atof(e) : kWideMinVisitRatio;
