@@ -149,22 +149,16 @@ void store_box(uint16_t q[3][2], const Box& b, const Grid& g) {
 // consecutive.
 struct WideCost {
     uint32_t first, n_items;  // the items below n: [first, first + n_items) in leaf order
-    bool as_leaf;             // cost(n, 1) is reached by turning n's whole subtree into one leaf
+    bool as_leaf;             // n is a leaf of the two-child tree
     double c[8];     // c[i], i = 1..7: cost(n, i)
     uint8_t k[9];    // k[j], j = 2..8: roots given to the left child when j are distributed over the two children
     uint8_t use[8];  // use[i], i = 2..7: the forest of cost(n, i) distributes this many (<= i; c(n, i - 1) may be as cheap)
 };
 
-// Cost of one leaf item relative to one visit of a wide node, and the most items a leaf of the wide
-// tree may hold (its meta byte counts them in unary, three bits).  RTX_WIDE_* in the environment
-// override them (experiments).
-double wide_leaf_cost() {
-    const char* e = std::getenv("RTX_WIDE_LEAF_COST");
-    return e ? std::atof(e) : 0.3;
-}
+// A leaf of the two-child tree (one record) becomes a leaf slot of a wide node; its cost is the
+// same in every forest, so it only has to be finite: kLeafCost times its area.
 void wide_costs(const std::vector<TmpNode>& nodes, std::vector<WideCost>& cost) {
-    const double kLeafCost = wide_leaf_cost();
-    constexpr uint32_t kMaxLeaf = 1;  // one record per leaf slot: the walk finds it by counting leaf slots
+    constexpr double kLeafCost = 0.3;
     cost.assign(nodes.size(), WideCost{});
     // children lie behind their parent in `nodes`: a backward pass is a post-order pass
     for (size_t n = nodes.size(); n-- > 0;) {
@@ -192,10 +186,6 @@ void wide_costs(const std::vector<TmpNode>& nodes, std::vector<WideCost>& cost) 
             }
         }
         C.c[1] = dist[8] + area;
-        if (C.n_items <= kMaxLeaf && area * kLeafCost * C.n_items < C.c[1]) {
-            C.c[1] = area * kLeafCost * C.n_items;
-            C.as_leaf = true;
-        }
         for (int i = 2; i <= 7; ++i) {
             if (dist[i] < C.c[i - 1]) {
                 C.c[i] = dist[i];
