@@ -2153,9 +2153,8 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     if (ref == kDone) phase = kDoneWalk;
                 }
                 if (leaves_now && at_leaf) {
-                    const uint32_t first = ref & kBvhLeafFirst, count = (ref >> kBvhLeafCountShift) & 15u;
-                    for (uint32_t k = 0; k < count; ++k)
-                        fast_leaf_item(sc, load_fast_item(sc.bvh_fast, first + k), ps.o, ps.d, inv, noi, kTMin, closest, best);
+                    // (a leaf of this tree is one record: rtx_bvh.cpp builds it with kLeafItems = 1)
+                    fast_leaf_item(sc, load_fast_item(sc.bvh_fast, ref & kBvhLeafFirst), ps.o, ps.d, inv, noi, kTMin, closest, best);
                     if (sp != 0u) {
                         --sp;
                         ref = s_stack2[sp][tid];
