@@ -2132,24 +2132,21 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 }
             } else {
                 if (at_node) {
+                    // Without branches: the top of the stack is fetched beside the node whether or not this
+                    // step pops it, and the farther child is written above the top whether or not both
+                    // children are met (sp only moves past it if they are; rtx_upload_scene refuses a tree
+                    // deeper than the stack, so that row exists).
+                    const uint32_t below = s_stack2[sp == 0u ? 0u : sp - 1u][tid];
                     const NodeWords N = load_node(sc, ref);
                     float n0, n1;
                     const bool h0 = slab_signed(N.a.x, N.a.y, N.a.z, br, kTMin, closest, n0);
                     const bool h1 = slab_signed(N.a.w, N.b.x, N.b.y, br, kTMin, closest, n1);
-                    // (rtx_upload_scene refuses a tree deeper than the stack: no bounds test here)
-                    if (h0 && h1) {  // the nearer child first, the other waits on the stack
-                        const bool first0 = n0 <= n1;
-                        s_stack2[sp][tid] = first0 ? N.b.w : N.b.z;
-                        ++sp;
-                        ref = first0 ? N.b.z : N.b.w;
-                    } else if (h0 || h1) {
-                        ref = h0 ? N.b.z : N.b.w;
-                    } else if (sp != 0u) {
-                        --sp;
-                        ref = s_stack2[sp][tid];
-                    } else {
-                        ref = kDone;
-                    }
+                    const bool both = h0 && h1, any = h0 || h1;
+                    const bool take0 = h0 && (!h1 || n0 <= n1);  // the nearer child first
+                    s_stack2[sp][tid] = take0 ? N.b.w : N.b.z;
+                    const bool pop = !any && sp != 0u;
+                    ref = any ? (take0 ? N.b.z : N.b.w) : (sp != 0u ? below : kDone);
+                    sp = sp + (both ? 1u : 0u) - (pop ? 1u : 0u);
                     if (ref == kDone) phase = kDoneWalk;
                 }
                 if (leaves_now && at_leaf) {
