@@ -2151,13 +2151,10 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 }
                 if (leaves_now && at_leaf) {
                     // (a leaf of this tree is one record: rtx_bvh.cpp builds it with kLeafItems = 1)
+                    const uint32_t below = s_stack2[sp == 0u ? 0u : sp - 1u][tid];  // fetched beside the record
                     fast_leaf_item(sc, load_fast_item(sc.bvh_fast, ref & kBvhLeafFirst), ps.o, ps.d, inv, noi, kTMin, closest, best);
-                    if (sp != 0u) {
-                        --sp;
-                        ref = s_stack2[sp][tid];
-                    } else {
-                        ref = kDone;
-                    }
+                    ref = sp != 0u ? below : kDone;
+                    sp -= sp != 0u ? 1u : 0u;
                     if (ref == kDone) phase = kDoneWalk;
                 }
             }
