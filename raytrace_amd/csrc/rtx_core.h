@@ -2127,8 +2127,14 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                     const uint32_t k = (uint32_t)__ffs((int)ig_bits) - 1u;
                     ig_bits &= ig_bits - 1u;
                     const uint32_t first = (ig_items & kWideItemBase) + (uint32_t)__popc(__builtin_amdgcn_ubfe(ig_items, 24u, k));
+                    const uint2 top = s_stack[sp == 0u ? 0u : sp - 1u][tid];  // fetched beside the record
                     fast_leaf_item(sc, load_fast_item(sc.wide_items, first), ps.o, ps.d, inv, noi, kTMin, closest, best);
-                    if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
+                    if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) {  // as RTX_NEXT_GROUP
+                        if (sp == 0u) phase = kDoneWalk;
+                        ng_base = sp != 0u ? top.x : ng_base;
+                        ng_bits = sp != 0u ? top.y : ng_bits;
+                        sp -= sp != 0u ? 1u : 0u;
+                    }
                 }
             } else {
                 if (at_node) {
