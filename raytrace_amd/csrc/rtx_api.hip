@@ -368,18 +368,20 @@ void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rt
     sr.push_back(sr.back());  // readable pad record
 }
 
-// Which tree the fast trace kernel walks.  A step down the eight-wide tree costs about three times the
+// Which tree the fast trace kernel walks.  A step down the eight-wide tree costs about five times the
 // instructions of a step down the two-child tree, so it pays when it saves enough steps: by the
 // surface-area estimates of the builder (expected node visits of a ray through the root box), the
 // wide tree is used when the two-child tree needs at least kWideMinVisitRatio times its visits.
-// Measured at 1080p, wide against two-child, Grays/s (ratio of the estimates): 487-sphere field 24.2 /
-// 27.9 (2.52); 200 / 500 / 1 000 / 2 000 / 5 000 / 20 000 items in a slab 52.0 / 53.5 (2.65), 42.6 / 42.9
-// (2.74), 34.0 / 36.2 (2.83), 28.8 / 29.2 (2.86), 21.9 / 21.7 (2.94), 13.9 / 13.6 (2.99) (tools/tree_sweep.sh);
-// 100 000 items 7.85 / 7.52 (3.04); with earlier kernels a 12-item Cornell box 19.4 / 17.7 (4.30), one
-// with 104 lights 9.6 / 8.6 (4.45).
+// Measured at 1080p, wide against two-child, Grays/s (ratio of the estimates): 200 / 2 000 / 5 000 /
+// 20 000 / 100 000 items in a slab 50.8 / 56.7 (2.65), 28.8 / 31.2 (2.86), 22.1 / 23.5 (2.94), 14.05 /
+// 14.74 (2.99), 8.75 / 8.84 (3.04, 1 024 spp per launch); a 12-item Cornell box with glass and metal
+// 23.2 / 24.4 (4.30); one with 47 items, most of them lights, 17.7 / 17.0 (4.48); the 9-item Cornell box
+// 29.0 / 28.4 (5.23) (tools/tree_sweep.sh, tools/gpu_time.py with RTX_WIDE_MIN_RATIO=0 / 100).  The
+// two-child walk has been the faster one on every tree of more than a few dozen items since its stack
+// lost its branches; scenes beyond 100 000 items have not been measured.
 // RTX_WIDE_MIN_RATIO and RTX_WIDE_MIN_ITEMS (scenes with fewer tree items walk the two-child tree)
 // override, for measurements and tests; RTX_TREE_STATS prints the estimates.
-constexpr double kWideMinVisitRatio = 2.9;
+constexpr double kWideMinVisitRatio = 4.4;
 double wide_min_ratio() {
     const char* e = std::getenv("RTX_WIDE_MIN_RATIO");  // read at every upload: tests switch it
     return e ? std::atof(e) : kWideMinVisitRatio;
