@@ -1869,6 +1869,10 @@ RTX_DEV uint32_t exchange_slots(uint32_t x, uint32_t swaps) {
 #ifndef RTX_SHADE_BATCH2
 #define RTX_SHADE_BATCH2 32
 #endif
+#ifndef RTX_SHADE_BATCH2_LONG
+#define RTX_SHADE_BATCH2_LONG 24  // trees of 8 192 nodes and more (launch_trace); 24 / 32 waiting lanes: 2 000 items
+                                  // 30.9 / 31.2 Grays/s, 20 000 items 14.8 / 14.6, 100 000 items 8.53 / 8.39 (16: 8.43, 40: 8.03)
+#endif
 #ifndef RTX_WALK_STEPS2
 #define RTX_WALK_STEPS2 8
 #endif
@@ -1903,7 +1907,7 @@ RTX_DEV uint32_t exchange_slots(uint32_t x, uint32_t swaps) {
 // sc.bvh_fast).  The wide tree's chain of dependent fetches is a third as long, but a step down
 // it costs about three times the instructions: it wins on large trees, the two-child tree on
 // small ones whose nodes all stay in the caches (see launch_trace).
-template <bool kLightTree, bool kSamples, bool kWide, bool kListLit = false>
+template <bool kLightTree, bool kSamples, bool kWide, bool kListLit = false, bool kLongWalks = false>
 __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel(const TraceArgs a) {
 #ifdef RTX_BVH_STATS
     uint32_t stat[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // wave-uniform
@@ -1976,7 +1980,8 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
         const unsigned long long idle = rtx_ballot(phase == kIdle);
         const bool pool_left = next < total;
         const uint32_t waiting = n_done + (pool_left ? (uint32_t)__popcll(idle) : 0u);
-        constexpr uint32_t kShadeBatch = kWide ? RTX_SHADE_BATCH : RTX_SHADE_BATCH2;
+        // (kLongWalks: a large two-child tree - the longer the walks, the sooner the finished lanes are shaded)
+        constexpr uint32_t kShadeBatch = kWide ? RTX_SHADE_BATCH : (kLongWalks ? RTX_SHADE_BATCH2_LONG : RTX_SHADE_BATCH2);
         if (waiting != 0u && (walking == 0ull || waiting >= kShadeBatch)) {
             RTX_STAT(5, 1u);      // [5] shade / refill passes of the wave
             RTX_STAT(6, n_done);  // [6] ... lanes shaded
