@@ -191,6 +191,12 @@ def parse_args(argv=None):
                          "use CPU tensors and the gloo backend, everything else (launch, sample split, pipelined "
                          "reduce, resolve, JSON line) is the code the GPU run uses")
     ap.add_argument("--dump-frame", default="", help="rank 0 saves the final fp32 SUM frame to this .npy file (tests)")
+    ap.add_argument("--rank-timeout", type=float, default=900.0,
+                    help="wall-clock deadline in seconds for a whole run (N > 1 ranks too): a parent that started the "
+                         "ranks kills them when it passes, a rank ends itself; either way the exit code is non-zero "
+                         "and stderr says where every rank was last seen")
+    ap.add_argument("--collective-timeout", type=float, default=180.0,
+                    help="timeout in seconds of the process group's rendezvous and collectives (N > 1)")
     return ap.parse_args(argv)
 
 
@@ -213,11 +219,16 @@ def launch_ranks(args) -> int:
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
+    import tempfile
+
+    trace_dir = tempfile.mkdtemp(prefix="rtx_bench_trace_")  # every rank keeps its last position here
+    deadline = time.monotonic() + args.rank_timeout
     procs = []
     for rank in range(n):
         env = dict(os.environ)
         env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RTX_BENCH_TRACE_FILE=os.path.join(trace_dir, f"rank{rank}.trace"))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
@@ -229,11 +240,13 @@ def launch_ranks(args) -> int:
     captured = []
     reader = threading.Thread(target=lambda: captured.append(procs[0].stdout.read()), daemon=True)
     reader.start()
+    timed_out = False
     while True:
         codes = [p.poll() for p in procs]
         if all(c is not None for c in codes):
             break
-        if any(c not in (None, 0) for c in codes):
+        timed_out = time.monotonic() > deadline
+        if timed_out or any(c not in (None, 0) for c in codes):
             for p in procs:  # exactly the children started above
                 if p.poll() is None:
                     p.kill()
@@ -241,6 +254,16 @@ def launch_ranks(args) -> int:
             break
         time.sleep(0.05)
     reader.join(timeout=10.0)
+    if timed_out:
+        print(f"bench.py: the ranks did not finish within --rank-timeout {args.rank_timeout:g} s; killed. "
+              "Last position of every rank:", file=sys.stderr)
+        for rank in range(n):
+            print(f"  rank {rank}: {last_trace_line(os.path.join(trace_dir, f'rank{rank}.trace'))}", file=sys.stderr)
+    import shutil
+
+    shutil.rmtree(trace_dir, ignore_errors=True)
+    if timed_out:
+        return 124
     out = captured[0] if captured else b""
     # rank 0's JSON line goes to stdout; anything else a library printed there (gloo and RCCL
     # announce themselves on stdout) goes to stderr, so that stdout stays the one line
@@ -251,6 +274,15 @@ def launch_ranks(args) -> int:
         print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
         return 1
     return 0
+
+
+def last_trace_line(path: str) -> str:
+    try:
+        with open(path) as f:
+            lines = f.read().splitlines()
+        return lines[-1] if lines else "(started, no position recorded)"
+    except OSError:
+        return "(never started)"
 
 
 def trace_kernel_name(mode: str, bvh: bool) -> str:
@@ -331,15 +363,41 @@ def main() -> int:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py with --gpus equal to the "
                          "number of ranks (or without a launcher: it starts its own ranks)")
 
+    trace_path = os.environ.get("RTX_BENCH_TRACE_FILE")
+    trace_file = open(trace_path, "a", buffering=1) if trace_path else None  # line-buffered
+    last_position = ["started"]
+
+    def trace(msg):  # where a rank is: kept for the deadline's report, on stderr with RTX_BENCH_TRACE=1
+        last_position[0] = msg
+        if trace_file:
+            trace_file.write(f"{time.strftime('%H:%M:%S')} {msg}\n")
+        if os.environ.get("RTX_BENCH_TRACE"):
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    # A rank's own deadline (the launcher may be torchrun, which has none): ranks parked in a collective
+    # must not run until the machine's lease ends.  os._exit ends the process without an exec and without
+    # waiting for the GPU queue; the launcher then stops the other ranks.
+    import threading
+
+    def expired():
+        print(f"bench.py: rank {rank} did not finish within --rank-timeout {args.rank_timeout:g} s; "
+              f"last position: {last_position[0]}", file=sys.stderr, flush=True)
+        os._exit(124)
+
+    watchdog = threading.Timer(args.rank_timeout, expired)
+    watchdog.daemon = True
+    watchdog.start()
+    trace("importing torch")
+
+    import datetime
+
     import torch
     import torch.distributed as dist
 
     from raytrace_amd import api
     from raytrace_amd.distributed import run_pipelined_steps, step_sample_range
 
-    def trace(msg):  # RTX_BENCH_TRACE=1: where a rank is, on stderr (a run that hangs says where)
-        if os.environ.get("RTX_BENCH_TRACE"):
-            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+    pg_timeout = datetime.timedelta(seconds=args.collective_timeout)
 
     scene_name, w, h, spp_default = WORKLOADS[args.workload]
     w, h = args.width or w, args.height or h
@@ -353,7 +411,8 @@ def main() -> int:
         engine = importlib.import_module(args.engine).make_engine(scene_name, w, h, args.mode)
         dev = torch.device("cpu")
         if world > 1:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
+        trace("process group up")
         ctx, bvh = None, False
     else:
         if not torch.cuda.is_available():
@@ -366,9 +425,9 @@ def main() -> int:
         dev = torch.device("cuda", local_rank)
         if world > 1:
             if args.backend == "nccl":
-                dist.init_process_group("nccl", device_id=dev)
+                dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
             else:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
         trace("process group up")
         ctx = api.Context(local_rank)
         scene = api.HostScene(scene_name, w, h)
@@ -551,8 +610,10 @@ def main() -> int:
         print(json.dumps(out), flush=True)
 
     if world > 1:
+        trace("final barrier")
         dist.barrier()
         dist.destroy_process_group()
+    watchdog.cancel()
     return 0
 
 

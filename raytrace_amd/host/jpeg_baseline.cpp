@@ -480,8 +480,10 @@ struct Decoder {
         while (p + 4 <= d.size()) {
             if (d[p] != 0xFF) return fail("marker expected");
             while (p + 1 < d.size() && d[p + 1] == 0xFF) ++p;  // fill bytes
+            if (p + 2 > d.size()) break;  // the file ends in fill bytes
             const int m = d[p + 1];
             if (m == 0xD9) break;
+            if (p + 4 > d.size()) return fail("segment cut short");  // the fill bytes used up the room for a length
             const size_t len = ((size_t)d[p + 2] << 8) | d[p + 3];
             const size_t body = p + 4, end = p + 2 + len;
             if (len < 2 || end > d.size()) return fail("segment cut short");

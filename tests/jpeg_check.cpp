@@ -18,6 +18,29 @@ static uint32_t rnd() {
     return g_state;
 }
 
+// Decodes a copy of `bytes` held in an allocation of exactly bytes.size() bytes: a std::vector that was
+// shrunk keeps its capacity, and the sanitizer does not see reads between size() and capacity().
+static int try_file(const std::vector<unsigned char>& bytes, long& decoded, long& refused) {
+    const std::vector<unsigned char> exact(bytes.begin(), bytes.end());
+    int bw = 0, bh = 0;
+    std::vector<unsigned char> out;
+    std::string err;
+    if (rt::detail::load_jpeg(exact, bw, bh, out, err)) {
+        if (out.size() != (size_t)bw * bh * 3) return 2;
+        ++decoded;
+    } else {
+        if (err.empty()) return 3;
+        ++refused;
+    }
+    return 0;
+}
+
+static size_t find_marker(const std::vector<unsigned char>& f, unsigned char m) {
+    for (size_t i = 2; i + 1 < f.size(); ++i)
+        if (f[i] == 0xFF && f[i + 1] == m) return i;
+    return 2;
+}
+
 int main(int argc, char** argv) {
     long decoded = 0, refused = 0;
     for (int a = 1; a < argc; ++a) {
@@ -52,15 +75,27 @@ int main(int argc, char** argv) {
                 const size_t head = bad.size() < 700 ? bad.size() : 700;
                 bad[rnd() % head] = (unsigned char)rnd();
             }
-            int bw = 0, bh = 0;
-            std::vector<unsigned char> out;
-            std::string err;
-            if (rt::detail::load_jpeg(bad, bw, bh, out, err)) {
-                if (out.size() != (size_t)bw * bh * 3) return 2;
-                ++decoded;
-            } else {
-                if (err.empty()) return 3;
-                ++refused;
+            const int rc = try_file(bad, decoded, refused);
+            if (rc) return rc;
+        }
+        // the marker walk at the end of a file: runs of fill bytes (0xFF) up to the last byte, and a
+        // marker behind fill bytes with fewer than the two length bytes left
+        const size_t sos = find_marker(file, 0xDA);
+        for (size_t keep : {(size_t)2, sos, file.size() - 2}) {
+            for (int fill = 1; fill <= 6; ++fill) {
+                std::vector<unsigned char> bad(file.begin(), file.begin() + keep);
+                bad.insert(bad.end(), (size_t)fill, 0xFF);
+                int rc = try_file(bad, decoded, refused);
+                if (rc) return rc;
+                for (unsigned char marker : {0xDB, 0xC4, 0xC0, 0xDA, 0xD9, 0xE0, 0x00}) {
+                    for (int tail = 0; tail <= 2; ++tail) {
+                        std::vector<unsigned char> b2 = bad;
+                        b2.push_back(marker);
+                        b2.insert(b2.end(), (size_t)tail, 0x00);
+                        rc = try_file(b2, decoded, refused);
+                        if (rc) return rc;
+                    }
+                }
             }
         }
     }

@@ -64,6 +64,44 @@ def test_a_rank_that_dies_ends_the_run_at_once():
     assert not any(ln.lstrip().startswith("{") for ln in r.stdout.splitlines())
 
 
+def test_a_rank_that_hangs_ends_the_run_inside_the_deadline():
+    """Rank 1 never returns from its first render step, so rank 0 parks in the reduce.  The parent
+    must kill both when --rank-timeout passes, fail, and say where each rank was."""
+    import time
+
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--spp-per-step", "1", "--rank-timeout", "25"] + COMMON,
+             env={"BENCH_ENGINE_HANG_RANK": "1"}, check=False)
+    assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
+    assert time.time() - t0 < 60.0
+    assert "--rank-timeout" in r.stderr and "rank 0:" in r.stderr and "rank 1:" in r.stderr
+    assert "reduce of step 0" in r.stderr  # rank 0 waits in the collective
+    assert not any(ln.lstrip().startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_a_hanging_rank_under_torchrun_ends_itself():
+    """Under torch.distributed.run there is no parent of ours: every rank carries the deadline."""
+    import socket
+    import time
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e["BENCH_ENGINE_HANG_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2",
+                        "--spp-per-step", "1", "--rank-timeout", "25"] + COMMON,
+                       env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0
+    assert time.time() - t0 < 90.0
+    assert "did not finish within --rank-timeout" in r.stderr
+    assert not any(ln.lstrip().startswith("{") for ln in r.stdout.splitlines())
+
+
 def test_world_size_must_match_gpus():
     r = _run(["--gpus", "2", "--spp-per-step", "1"] + COMMON, env={"WORLD_SIZE": "1", "RANK": "0"}, check=False)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
