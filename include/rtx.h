@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 4u
+#define RTX_ABI_VERSION 5u
 
 typedef enum RtxStatus {
     RTX_OK = 0,
@@ -214,8 +214,9 @@ int rtx_render(RtxContext* ctx, const RtxParams* params, float* accum_rgb, uint6
 
 /*
  * rtx_render without any allocation.  No counterpart in the reference: it is for callers that
- * cannot allocate device memory at the time of the call (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  The device-side accumulator and ray counter,
+ * cannot allocate device memory at the time of the call (tight serving loops, harnesses that
+ * forbid hipMalloc; the call itself still copies and synchronises, so it is not for use inside a
+ * stream capture).  The device-side accumulator and ray counter,
  * which rtx_render keeps in buffers its context allocates on first use, live in one file-scope
  * device array of the library instead (RTX_NOALLOC_MAX_PIXELS * 12 + 256 bytes, held by every
  * GPU the process has created a context on until the process ends); the call makes no hipMalloc,
@@ -231,8 +232,10 @@ int rtx_render_noalloc(RtxContext* ctx, const RtxParams* params, float* accum_rg
  * [spp_begin, spp_begin+spp_count) is cut into n_ctx contiguous blocks (the first
  * spp_count % n_ctx blocks one sample longer), block i is rendered by ctxs[i] on that
  * context's device, all devices at the same time; the partial sums are copied
- * device-to-device to ctxs[0]'s GPU and added there in context order, so the result does
- * not depend on timing.  Samples are keyed by their absolute index: up to the order of the
+ * device-to-device to ctxs[0]'s GPU (hipMemcpyPeerAsync, one copy per context over its own
+ * link; no RCCL in this library: a 1080p frame is 24.9 MB per GPU, and a process that wants
+ * the ring reduce runs one rank per GPU over torch.distributed instead) and added there in
+ * context order, so the result does not depend on timing.  Samples are keyed by their absolute index: up to the order of the
  * fp32 additions the frame is the one rtx_render makes on one GPU.  Every context must
  * hold the same scene (rtx_upload_scene on each); two contexts may share a device.
  * The reference has one loop nest on one host (Scene.cpp:137-153; its OpenMP pragma over
@@ -292,6 +295,9 @@ typedef struct RtxSceneInfo {
     uint32_t n_items;      /* top-level BVH items (single primitives or whole transformed instances) */
     uint32_t n_bvh_nodes;  /* 0 when the linear scan is used */
     uint32_t accel;        /* RTX_ACCEL_LINEAR or RTX_ACCEL_BVH actually in use */
+    uint32_t bvh_depth;    /* inner-node levels above the deepest leaf; 0 without a tree */
+    float bvh_visits;      /* the builder's surface-area estimate of the inner nodes a ray through the
+                              root box visits (sum of the inner nodes' areas / the root's area) */
 } RtxSceneInfo;
 int rtx_scene_info(RtxContext* ctx, RtxSceneInfo* out);
 

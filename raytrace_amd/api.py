@@ -15,7 +15,7 @@ import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
-RTX_ABI_VERSION = 4
+RTX_ABI_VERSION = 5
 RTX_ACCEL_AUTO, RTX_ACCEL_LINEAR, RTX_ACCEL_BVH = 0, 1, 2
 RTX_MODE_FAST, RTX_MODE_DETERMINISTIC = 0, 1
 RTX_PRIM_RECT_XY, RTX_PRIM_RECT_XZ, RTX_PRIM_RECT_YZ, RTX_PRIM_SPHERE = 0, 1, 2, 3
@@ -87,7 +87,8 @@ class RtxHit(C.Structure):
 
 class RtxSceneInfo(C.Structure):
     _fields_ = [("n_prims", C.c_uint32), ("n_items", C.c_uint32),
-                ("n_bvh_nodes", C.c_uint32), ("accel", C.c_uint32)]
+                ("n_bvh_nodes", C.c_uint32), ("accel", C.c_uint32),
+                ("bvh_depth", C.c_uint32), ("bvh_visits", C.c_float)]
 
 
 HIT_DTYPE = np.dtype([("hit", "<i4"), ("prim", "<i4"), ("t", "<f4"),

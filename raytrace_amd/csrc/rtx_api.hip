@@ -109,8 +109,6 @@ struct RtxContext {
     DeviceArray<rtxd::BvhMap> bvh_maps;
     DeviceArray<uint32_t> scan_orig;
     DeviceArray<rtxd::BvhNode> bvh;
-    DeviceArray<rtxd::WideNode> bvh_wide;
-    DeviceArray<rtxd::BvhFastItem> wide_items;
     DeviceArray<rtxd::Group> bvh_items;
     // scratch owned by the host-buffer entry points
     DeviceArray<float> accum;
@@ -366,29 +364,6 @@ void build_scan_table(const std::vector<rtxd::Prim>& prims, const std::vector<rt
         sg.push_back(S);
     }
     sr.push_back(sr.back());  // readable pad record
-}
-
-// Which tree the fast trace kernel walks.  A step down the eight-wide tree costs about five times the
-// instructions of a step down the two-child tree, so it pays when it saves enough steps: by the
-// surface-area estimates of the builder (expected node visits of a ray through the root box), the
-// wide tree is used when the two-child tree needs at least kWideMinVisitRatio times its visits.
-// Measured at 1080p, wide against two-child, Grays/s (ratio of the estimates): 200 / 2 000 / 5 000 /
-// 20 000 / 100 000 items in a slab 50.8 / 56.7 (2.65), 28.8 / 31.2 (2.86), 22.1 / 23.5 (2.94), 14.05 /
-// 14.74 (2.99), 8.75 / 8.84 (3.04, 1 024 spp per launch); a 12-item Cornell box with glass and metal
-// 23.2 / 24.4 (4.30); one with 47 items, most of them lights, 17.7 / 17.0 (4.48); the 9-item Cornell box
-// 29.0 / 28.4 (5.23) (tools/tree_sweep.sh, tools/gpu_time.py with RTX_WIDE_MIN_RATIO=0 / 100).  The
-// two-child walk has been the faster one on every tree of more than a few dozen items since its stack
-// lost its branches; scenes beyond 100 000 items have not been measured.
-// RTX_WIDE_MIN_RATIO and RTX_WIDE_MIN_ITEMS (scenes with fewer tree items walk the two-child tree)
-// override, for measurements and tests; RTX_TREE_STATS prints the estimates.
-constexpr double kWideMinVisitRatio = 4.4;
-double wide_min_ratio() {
-    const char* e = std::getenv("RTX_WIDE_MIN_RATIO");  // read at every upload: tests switch it
-    return e ? std::atof(e) : kWideMinVisitRatio;
-}
-size_t wide_min_items() {
-    const char* e = std::getenv("RTX_WIDE_MIN_ITEMS");
-    return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0;
 }
 
 // Fast-mode leaf records of the BVH items (groups in leaf order) and the hit-completion table
@@ -716,7 +691,6 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     std::vector<rtxd::Group>& items = tree.items;  // leaf order, then the items outside the tree
     std::vector<rtxd::BvhFastItem> fast_items;
     std::vector<rtxd::BvhMap> fast_maps;
-    std::vector<rtxd::BvhFastItem> wide_items;
     if (use_bvh) {
         std::string err;
         if (!rtxbvh::build(prims, groups, steps, tree, err)) return fail(RTX_ERR_TOO_LARGE, err);
@@ -724,26 +698,11 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
         if (tree.depth + 1 > rtxd::kBvhStackEntries)
             return fail(RTX_ERR_TOO_LARGE, "BVH is deeper than the traversal stack");
         build_bvh_fast_items(prims, info, items, steps, fast_items, fast_maps, scan_info, scan_orig);
-        if (std::getenv("RTX_TREE_STATS"))
-            std::fprintf(stderr, "rtx tree: %zu items, %zu two-child nodes (depth %d, %.2f visits), %zu wide nodes (%.2f visits), ratio %.2f\n",
-                         items.size(), tree.nodes.size(), tree.depth, tree.visits_two_child, tree.wide.size(), tree.visits_wide,
-                         tree.visits_wide > 0.0 ? tree.visits_two_child / tree.visits_wide : 0.0);
-        // the eight-wide tree of the fast trace kernel reads the leaf records in its own order; a
-        // tree deeper than that kernel's stack, one of 2^24 records or more, or one that saves too few steps (see
-        // kWideMinVisitRatio), is rendered through the two-child tree instead
-        const bool wide_pays = tree.visits_wide > 0.0 && tree.visits_two_child >= wide_min_ratio() * tree.visits_wide;
-        if (tree.wide_depth <= rtxd::kWideStackEntries && items.size() >= wide_min_items() && wide_pays &&
-            tree.wide_order.size() <= rtxd::kWideItemBase) {
-            wide_items.reserve(tree.wide_order.size());
-            for (uint32_t k : tree.wide_order) wide_items.push_back(fast_items[k]);
-        } else {
-            tree.wide.clear();
-        }
     }
 
     // the kernels address these tables per lane with 32-bit byte offsets
     if (scan_info.size() * sizeof(rtxd::ScanHit) >= (1ull << 32) || fast_items.size() * sizeof(rtxd::BvhFastItem) >= (1ull << 32) ||
-        tree.wide.size() * sizeof(rtxd::WideNode) >= (1ull << 32) || nodes.size() * sizeof(rtxd::BvhNode) >= (1ull << 32) ||
+        nodes.size() * sizeof(rtxd::BvhNode) >= (1ull << 32) ||
         lights.size() * sizeof(rtxd::Light) >= (1ull << 32) || fast_maps.size() * sizeof(rtxd::BvhMap) >= (1ull << 32) ||
         prims_padded.size() * sizeof(rtxd::Prim) >= (1ull << 32))
         return fail(RTX_ERR_TOO_LARGE, "a scene table exceeds 4 GiB");
@@ -762,8 +721,6 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     RTX_HIP(ctx->scan_info.upload(scan_info));
     RTX_HIP(ctx->scan_orig.upload(scan_orig));
     RTX_HIP(ctx->bvh.upload(nodes));
-    RTX_HIP(ctx->bvh_wide.upload(tree.wide));
-    RTX_HIP(ctx->wide_items.upload(wide_items));
     RTX_HIP(ctx->bvh_items.upload(items));
     RTX_HIP(ctx->bvh_fast.upload(fast_items));
     RTX_HIP(ctx->bvh_maps.upload(fast_maps));
@@ -787,8 +744,6 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     v.bvh_items = use_bvh ? ctx->bvh_items.ptr : nullptr;
     v.bvh_fast = use_bvh ? ctx->bvh_fast.ptr : nullptr;
     v.bvh_maps = use_bvh ? ctx->bvh_maps.ptr : nullptr;
-    v.bvh_wide = use_bvh && !tree.wide.empty() ? ctx->bvh_wide.ptr : nullptr;
-    v.wide_items = use_bvh ? ctx->wide_items.ptr : nullptr;
     std::memcpy(v.bvh_origin, tree.origin, sizeof v.bvh_origin);
     std::memcpy(v.bvh_scale, tree.scale, sizeof v.bvh_scale);
     v.n_bvh_big = tree.n_big;
@@ -821,6 +776,8 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     ctx->info.n_items = (uint32_t)groups.size();
     ctx->info.n_bvh_nodes = (uint32_t)nodes.size();
     ctx->info.accel = use_bvh ? RTX_ACCEL_BVH : RTX_ACCEL_LINEAR;
+    ctx->info.bvh_depth = use_bvh ? (uint32_t)tree.depth : 0u;
+    ctx->info.bvh_visits = use_bvh ? (float)tree.visits : 0.0f;
     ctx->scene_hash = hash_scene(s, use_bvh);
     ctx->has_scene = true;
     return RTX_OK;

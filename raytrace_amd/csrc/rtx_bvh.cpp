@@ -139,190 +139,6 @@ void store_box(uint16_t q[3][2], const Box& b, const Grid& g) {
     }
 }
 
-// Collapse the two-child tree into eight-wide nodes.  Which inner nodes of the two-child tree
-// survive as wide nodes is chosen by dynamic programming over the surface-area cost (Ylitie et
-// al. 2017, section 4.1): cost(n, i) = the cheapest way to turn n's subtree into a forest of at
-// most i roots (wide nodes or leaves), where a wide node costs its area and a leaf kLeafCost times
-// its area; a wide node at n is the cheapest forest of at most eight roots below n plus n's own
-// area.  Against opening the largest child first this fills the nodes better (fewer of them,
-// fewer steps per ray).  Breadth-first emission, so that the inner children of a node are
-// consecutive.
-struct WideCost {
-    uint32_t first, n_items;  // the items below n: [first, first + n_items) in leaf order
-    bool as_leaf;             // n is a leaf of the two-child tree
-    double c[8];     // c[i], i = 1..7: cost(n, i)
-    uint8_t k[9];    // k[j], j = 2..8: roots given to the left child when j are distributed over the two children
-    uint8_t use[8];  // use[i], i = 2..7: the forest of cost(n, i) distributes this many (<= i; c(n, i - 1) may be as cheap)
-};
-
-// A leaf of the two-child tree (one record) becomes a leaf slot of a wide node; its cost is the
-// same in every forest, so it only has to be finite: kLeafCost times its area.
-void wide_costs(const std::vector<TmpNode>& nodes, std::vector<WideCost>& cost) {
-    constexpr double kLeafCost = 0.3;
-    cost.assign(nodes.size(), WideCost{});
-    // children lie behind their parent in `nodes`: a backward pass is a post-order pass
-    for (size_t n = nodes.size(); n-- > 0;) {
-        WideCost& C = cost[n];
-        const double area = nodes[n].box.area();
-        if (nodes[n].count != 0) {
-            C.first = nodes[n].left;
-            C.n_items = nodes[n].count;
-            C.as_leaf = true;
-            for (int i = 1; i <= 7; ++i) C.c[i] = area * kLeafCost * C.n_items;
-            continue;
-        }
-        const WideCost &L = cost[nodes[n].left], &R = cost[nodes[n].left + 1];
-        C.first = L.first;  // the left child's items come first and the right child's follow them
-        C.n_items = L.n_items + R.n_items;
-        double dist[9];
-        for (int j = 2; j <= 8; ++j) {
-            dist[j] = DBL_MAX;
-            for (int k = std::max(1, j - 7); k <= std::min(7, j - 1); ++k) {
-                const double v = L.c[k] + R.c[j - k];
-                if (v < dist[j]) {
-                    dist[j] = v;
-                    C.k[j] = (uint8_t)k;
-                }
-            }
-        }
-        C.c[1] = dist[8] + area;
-        for (int i = 2; i <= 7; ++i) {
-            if (dist[i] < C.c[i - 1]) {
-                C.c[i] = dist[i];
-                C.use[i] = (uint8_t)i;
-            } else {
-                C.c[i] = C.c[i - 1];
-                C.use[i] = i == 2 ? (uint8_t)1 : C.use[i - 1];
-            }
-        }
-        C.use[1] = 1;
-    }
-}
-
-// The roots of the forest of cost(n, i).
-void wide_forest(const std::vector<TmpNode>& nodes, const std::vector<WideCost>& cost, uint32_t n, int i,
-                 std::vector<uint32_t>& out) {
-    if (nodes[n].count != 0) {
-        out.push_back(n);
-        return;
-    }
-    const int j = i >= 2 ? cost[n].use[i] : 1;
-    if (j <= 1) {  // n itself is a root: a wide node
-        out.push_back(n);
-        return;
-    }
-    const int k = cost[n].k[j];
-    wide_forest(nodes, cost, nodes[n].left, k, out);
-    wide_forest(nodes, cost, nodes[n].left + 1, j - k, out);
-}
-
-void build_wide(const std::vector<TmpNode>& nodes, Tree& out) {
-    struct Pending {
-        uint32_t wide, tmp;
-        int depth;
-    };
-    std::vector<WideCost> cost;
-    wide_costs(nodes, cost);
-    out.wide.clear();
-    out.wide_order.clear();
-    out.wide_depth = 0;
-    out.wide_area_sum = 0.0;
-    out.wide.emplace_back();
-    std::vector<Pending> queue;
-    queue.push_back(Pending{0, 0, 1});
-    for (size_t head = 0; head < queue.size(); ++head) {
-        const Pending cur = queue[head];
-        out.wide_depth = std::max(out.wide_depth, cur.depth);
-        std::vector<uint32_t> kids;
-        if (cost[cur.tmp].as_leaf) {
-            kids.push_back(cur.tmp);  // the whole tree is one leaf
-        } else {  // the cheapest forest of at most eight roots below this node
-            const int k = cost[cur.tmp].k[8];
-            wide_forest(nodes, cost, nodes[cur.tmp].left, k, kids);
-            wide_forest(nodes, cost, nodes[cur.tmp].left + 1, 8 - k, kids);
-        }
-        Box box;
-        for (uint32_t k : kids) box.add(nodes[k].box);
-        out.wide_area_sum += box.area();
-        // slots: child c goes where (centre_c - centre_node) . (+-1, +-1, +-1)_slot is largest, greedily
-        double centre[3];
-        for (int a = 0; a < 3; ++a) centre[a] = 0.5 * (box.lo[a] + box.hi[a]);
-        int slot_of[8], child_in[8];
-        for (int k = 0; k < 8; ++k) slot_of[k] = child_in[k] = -1;
-        for (size_t round = 0; round < kids.size(); ++round) {
-            double best = -DBL_MAX;
-            int bc = -1, bs = -1;
-            for (size_t c = 0; c < kids.size(); ++c) {
-                if (slot_of[c] >= 0) continue;
-                const Box& b = nodes[kids[c]].box;
-                for (int sidx = 0; sidx < 8; ++sidx) {
-                    if (child_in[sidx] >= 0) continue;
-                    double cost = 0.0;
-                    for (int a = 0; a < 3; ++a)
-                        cost += (0.5 * (b.lo[a] + b.hi[a]) - centre[a]) * (((sidx >> a) & 1) ? 1.0 : -1.0);
-                    if (cost > best) {
-                        best = cost;
-                        bc = (int)c;
-                        bs = sidx;
-                    }
-                }
-            }
-            slot_of[bc] = bs;
-            child_in[bs] = bc;
-        }
-        // the node's grid: p below the box, step 2^e per axis with (hi - p) / 2^e <= 255
-        rtxd::WideNode W{};
-        double step[3];
-        for (int a = 0; a < 3; ++a) {
-            W.p[a] = std::nextafterf((float)box.lo[a], -FLT_MAX);
-            const double ext = std::max(box.hi[a] - (double)W.p[a], 1e-30);
-            int e = (int)std::ceil(std::log2(ext / 255.0));
-            e = std::min(std::max(e, -100), 100);
-            while (ext / std::ldexp(1.0, e) > 255.0) ++e;
-            W.e[a] = (uint8_t)(e + 127);
-            step[a] = std::ldexp(1.0, e);
-        }
-        const uint32_t item_base = (uint32_t)out.wide_order.size();
-        uint32_t leaf_slots = 0;
-        uint32_t n_inner = 0;
-        for (int sidx = 0; sidx < 8; ++sidx) {
-            for (int a = 0; a < 3; ++a) {  // an empty slot: an inverted box no ray meets
-                W.qlo[a][sidx] = 255;
-                W.qhi[a][sidx] = 0;
-            }
-            if (child_in[sidx] < 0) continue;
-            const TmpNode& C = nodes[kids[child_in[sidx]]];
-            const WideCost& K = cost[kids[child_in[sidx]]];
-            for (int a = 0; a < 3; ++a) {
-                const double l = std::floor((C.box.lo[a] - (double)W.p[a]) / step[a]);
-                const double h = std::ceil((C.box.hi[a] - (double)W.p[a]) / step[a]);
-                W.qlo[a][sidx] = (uint8_t)std::min(std::max(l, 0.0), 255.0);
-                W.qhi[a][sidx] = (uint8_t)std::min(std::max(h, 0.0), 255.0);
-            }
-            if (!K.as_leaf) {
-                W.imask |= (uint8_t)(1u << sidx);
-                W.meta[sidx] = (uint8_t)(0x20u | (24u + (uint32_t)sidx));
-                ++n_inner;
-            } else {
-                const uint32_t offset = (uint32_t)out.wide_order.size() - item_base;  // = leaf slots below this one
-                W.meta[sidx] = (uint8_t)(0x20u | offset);
-                leaf_slots |= 1u << sidx;
-                out.wide_order.push_back(K.first);  // K.n_items == 1
-            }
-        }
-        W.items = (item_base & rtxd::kWideItemBase) | (leaf_slots << 24);
-        W.child_base = (uint32_t)out.wide.size();
-        out.wide.resize(out.wide.size() + n_inner);
-        uint32_t rel = 0;
-        for (int sidx = 0; sidx < 8; ++sidx) {
-            if (!(W.imask & (1u << sidx))) continue;
-            queue.push_back(Pending{W.child_base + rel, kids[child_in[sidx]], cur.depth + 1});
-            ++rel;
-        }
-        out.wide[cur.wide] = W;
-    }
-}
-
 }  // namespace
 
 bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,
@@ -488,15 +304,13 @@ bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>&
         err = "too many BVH items";
         return false;
     }
-    static_assert(kLeafItems == 1, "a wide node's leaf slot holds one record");
-    build_wide(nodes, out);
+    static_assert(kLeafItems == 1, "the fast trace kernel reads one record per leaf");
     {   // expected node visits of a ray through the root box, by the surface-area measure
         const double root = nodes[0].box.area();
-        double two = 0.0;
+        double sum = 0.0;
         for (const TmpNode& N : nodes)
-            if (N.count == 0) two += N.box.area();
-        out.visits_two_child = root > 0.0 ? two / root : 0.0;
-        out.visits_wide = root > 0.0 ? out.wide_area_sum / root : 0.0;
+            if (N.count == 0) sum += N.box.area();
+        out.visits = root > 0.0 ? sum / root : 0.0;
     }
     if (nodes[0].count != 0) {
         // a single leaf: root node with one real child and one empty box

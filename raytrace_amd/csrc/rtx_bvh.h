@@ -31,15 +31,9 @@ struct Tree {
     std::vector<rtxd::Group> items;
     uint32_t n_big = 0;
     int depth = 0;  // inner-node levels above the deepest leaf
-    // the same tree collapsed into eight-wide nodes (rtxd::WideNode): wide[0] is the root,
-    // wide_order[k] = position in `items` of the wide tree's k-th leaf record, wide_depth =
-    // levels of wide nodes (what the wide traversal's stack has to hold)
-    std::vector<rtxd::WideNode> wide;
-    std::vector<uint32_t> wide_order;
-    int wide_depth = 0;
-    // surface-area estimates: the inner nodes of the two-child tree / the nodes of the wide tree a
-    // ray through the root box visits on average (sum of node areas over the root's area)
-    double visits_two_child = 0.0, visits_wide = 0.0, wide_area_sum = 0.0;
+    // surface-area estimate: the inner nodes a ray through the root box visits on average (sum of
+    // the inner nodes' areas over the root's area)
+    double visits = 0.0;
     float origin[3] = {0, 0, 0};
     float scale[3] = {1, 1, 1};
 };

@@ -1769,85 +1769,6 @@ __attribute__((amdgpu_num_sgpr(RTX_TRACE_SGPRS))) __global__ void __launch_bound
 }
 
 #if !RTX_DET
-// ---------------------------------------------------------------------------
-// eight-wide tree (rtxd::WideNode): one node against one ray
-// ---------------------------------------------------------------------------
-// Byte k of a word as a float (v_cvt_f32_ubyte0..3).
-template <int K>
-RTX_DEV float ubyte(uint32_t w) { return (float)((w >> (8 * K)) & 0xffu); }
-
-// Child K of four (the near / far plane bytes of the three axes, four children per word).  A
-// child's box on the node's grid is p + q * 2^e; along the ray that is
-// t(q) = q * (2^e * inv) + (p * inv + noi), one conversion and one fma per plane.  Which of the
-// two planes of an axis the ray meets first depends only on the sign of its direction, so the
-// caller hands over the near and far bytes already selected: no min / max per axis.  The
-// outcome is shifted into `hits` from below (compare into vcc, add with carry: one full-rate
-// instruction instead of a select, a shift and an or per child).
-template <int K>
-RTX_DEV uint32_t wide_child(uint32_t xn, uint32_t yn, uint32_t zn, uint32_t xf, uint32_t yf, uint32_t zf, V3 s, V3 b,
-                            float t0, float closest, uint32_t hits) {
-    const float tnx = __builtin_fmaf(ubyte<K>(xn), s.x, b.x), tny = __builtin_fmaf(ubyte<K>(yn), s.y, b.y),
-                tnz = __builtin_fmaf(ubyte<K>(zn), s.z, b.z);
-    const float tfx = __builtin_fmaf(ubyte<K>(xf), s.x, b.x), tfy = __builtin_fmaf(ubyte<K>(yf), s.y, b.y),
-                tfz = __builtin_fmaf(ubyte<K>(zf), s.z, b.z);
-    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz), t0);
-    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(tfx, tfy), tfz), closest);
-    asm("v_cmp_le_f32 vcc, %1, %2\n\t"
-        "v_addc_co_u32 %0, vcc, %0, %0, vcc"
-        : "+v"(hits)
-        : "v"(tn), "v"(tf)
-        : "vcc");
-    return hits;
-}
-
-// The slots of one node whose box the ray meets (bit s = slot s; an empty slot holds an
-// inverted box that no ray meets).
-RTX_DEV uint32_t wide_node_hits(uint4 n0, uint4 n2, uint4 n3, uint4 n4, V3 inv, V3 noi, float t0, float closest) {
-    V3 s, b;
-    s.x = __uint_as_float((n0.w & 0xffu) << 23) * inv.x;
-    s.y = __uint_as_float((n0.w & 0xff00u) << 15) * inv.y;
-    s.z = __uint_as_float((n0.w & 0xff0000u) << 7) * inv.z;
-    b.x = __builtin_fmaf(__uint_as_float(n0.x), inv.x, noi.x);
-    b.y = __builtin_fmaf(__uint_as_float(n0.y), inv.y, noi.y);
-    b.z = __builtin_fmaf(__uint_as_float(n0.z), inv.z, noi.z);
-    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
-    // words: n2 = qlo.x[0-3] qlo.x[4-7] qlo.y[0-3] qlo.y[4-7]; n3 = qlo.z.. qlo.z.. qhi.x.. qhi.x..;
-    //        n4 = qhi.y.. qhi.y.. qhi.z.. qhi.z..
-    uint32_t hits = 0u;  // slot 7 first: it ends up in bit 7
-    {
-        const uint32_t xn = nx ? n3.w : n2.y, xf = nx ? n2.y : n3.w;
-        const uint32_t yn = ny ? n4.y : n2.w, yf = ny ? n2.w : n4.y;
-        const uint32_t zn = nz ? n4.w : n3.y, zf = nz ? n3.y : n4.w;
-        hits = wide_child<3>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
-        hits = wide_child<2>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
-        hits = wide_child<1>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
-        hits = wide_child<0>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
-    }
-    {
-        const uint32_t xn = nx ? n3.z : n2.x, xf = nx ? n2.x : n3.z;
-        const uint32_t yn = ny ? n4.x : n2.z, yf = ny ? n2.z : n4.x;
-        const uint32_t zn = nz ? n4.z : n3.x, zf = nz ? n3.x : n4.z;
-        hits = wide_child<3>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
-        hits = wide_child<2>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
-        hits = wide_child<1>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
-        hits = wide_child<0>(xn, yn, zn, xf, yf, zf, s, b, t0, closest, hits);
-    }
-    return hits;
-}
-
-// Bits of a byte moved from position s to position s ^ c: one conditional exchange per bit of c
-// (neighbours, pairs, halves).  `swaps` holds the three exchange masks of the ray's c - 0x55,
-// 0x33, 0x0f where the bit of c is set, else 0 - in its bytes 0, 1, 2.
-RTX_DEV uint32_t exchange_slots(uint32_t x, uint32_t swaps) {
-    uint32_t t = ((x >> 1) ^ x) & (swaps & 0xffu);
-    x ^= t + (t << 1);
-    t = ((x >> 2) ^ x) & ((swaps >> 8) & 0xffu);
-    x ^= t + (t << 2);
-    t = ((x >> 4) ^ x) & ((swaps >> 16) & 0xffu);
-    x ^= t + (t << 4);
-    return x;
-}
-
 // BVH scenes, fast mode: the same pool of (pixel, sample) items per wave, but traversal and
 // shading are decoupled.  A lane is idle, traversing, or holds a finished nearest-hit query;
 // each iteration of the wave performs ONE traversal step (a node, or a leaf) for the lanes
@@ -1857,31 +1778,23 @@ RTX_DEV uint32_t exchange_slots(uint32_t x, uint32_t swaps) {
 // by an order of magnitude: in trace_kernel every lane waits for the longest of the wave's
 // 64 queries before any of them is shaded, here a lane that is done is refilled while the
 // others walk on, and the scattering code runs on a well-filled wave.
-#ifndef RTX_SHADE_BATCH
-#define RTX_SHADE_BATCH 24  // measured 8 .. 56 (one item per leaf, 32-byte nodes): 16 best on the 100k-item
-                            // scene (5.52 Grays/s), 32 on the 487-sphere field; 24: 5.45 / 20.9
-#endif
-#ifndef RTX_WALK_STEPS
-#define RTX_WALK_STEPS 4    // traversal steps between two looks at the wave's state (1 .. 16 measured)
-#endif
-// ... and for the two-child tree, whose steps are a third as long (487-sphere field: 4 / 8 / 16 walk
-// steps 22.5 / 23.5 / 23.2 Grays/s, shade batch 16 / 24 / 32 20.8 / 22.5 / 23.1)
+// Scheduling constants, measured on the 487-sphere field and on slabs of 2 000 - 100 000 items at 1080p:
+// walk steps between two looks at the wave's state 4 / 8 / 16: 22.5 / 23.5 / 23.2 Grays/s (sphere field);
+// lanes that must wait before a shading pass runs 16 / 24 / 32: 20.8 / 22.5 / 23.1 (sphere field), on trees of
+// 8 192 nodes and more (kLongWalks; the longer the walks, the sooner the finished lanes should be shaded)
+// 24 / 32: 14.8 / 14.6 (20 000 items), 8.53 / 8.39 (100 000 items; 16: 8.43, 40: 8.03), but 30.9 / 31.2 on
+// 2 000 items; lanes that must hold a leaf record before the leaf code runs: 4 .. 32 measured, 8 best.
 #ifndef RTX_SHADE_BATCH2
 #define RTX_SHADE_BATCH2 32
 #endif
 #ifndef RTX_SHADE_BATCH2_LONG
-#define RTX_SHADE_BATCH2_LONG 24  // trees of 8 192 nodes and more (launch_trace); 24 / 32 waiting lanes: 2 000 items
-                                  // 30.9 / 31.2 Grays/s, 20 000 items 14.8 / 14.6, 100 000 items 8.53 / 8.39 (16: 8.43, 40: 8.03)
+#define RTX_SHADE_BATCH2_LONG 24
 #endif
 #ifndef RTX_WALK_STEPS2
 #define RTX_WALK_STEPS2 8
 #endif
 #ifndef RTX_LEAF_BATCH
-#define RTX_LEAF_BATCH 8  // two-child walk; measured 4 .. 32
-#endif
-#ifndef RTX_LEAF_BATCH_WIDE
-#define RTX_LEAF_BATCH_WIDE 12  // wide walk: 100 000 items 7.22 / 7.52 / 7.59 Grays/s with 8 / 12 / 16, 20 000 items
-                                // 13.01 / 13.01 / 12.83
+#define RTX_LEAF_BATCH 8
 #endif
 // One wave per block: a block's LDS and wave slots are free as soon as ITS pool is spent (the
 // waves of a 256-thread block wait for the slowest of the four).  Six waves per SIMD are 24
@@ -1903,22 +1816,17 @@ RTX_DEV uint32_t exchange_slots(uint32_t x, uint32_t swaps) {
 #define RTX_STAT(i, n) ((void)0)
 #endif
 
-// kWide: the eight-wide tree (sc.bvh_wide / sc.wide_items), else the two-child tree (sc.bvh /
-// sc.bvh_fast).  The wide tree's chain of dependent fetches is a third as long, but a step down
-// it costs about three times the instructions: it wins on large trees, the two-child tree on
-// small ones whose nodes all stay in the caches (see launch_trace).
-template <bool kLightTree, bool kSamples, bool kWide, bool kListLit = false, bool kLongWalks = false>
+// The kernel walks the two-child tree of the deterministic mode (sc.bvh) and reads the fast-mode
+// leaf records (sc.bvh_fast).  kLongWalks: see the scheduling constants above.
+template <bool kLightTree, bool kSamples, bool kListLit = false, bool kLongWalks = false>
 __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel(const TraceArgs a) {
 #ifdef RTX_BVH_STATS
     uint32_t stat[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // wave-uniform
 #endif
     __shared__ float s_acc[RTX_BVH_BLOCK / 64][3][64];
-    // per lane: the node groups of the levels above that still have children to visit (wide
-    // tree), or the deferred children (two-child tree; the same 5.5 KB per wave either way)
-    __shared__ uint2 s_stack[kWideStackEntries][RTX_BVH_BLOCK];
-    static_assert(sizeof(uint2) * kWideStackEntries == sizeof(uint32_t) * kBvhStack, "one LDS block, two views");
-    static_assert((sizeof(s_stack) + sizeof(s_acc)) * 4 * RTX_BVH_WAVES <= 160 * 1024, "LDS must not bound the occupancy");
-    uint32_t (*s_stack2)[RTX_BVH_BLOCK] = reinterpret_cast<uint32_t (*)[RTX_BVH_BLOCK]>(&s_stack[0][0]);
+    // per lane: the deferred children, one per level
+    __shared__ uint32_t s_stack2[kBvhStack][RTX_BVH_BLOCK];
+    static_assert((sizeof(s_stack2) + sizeof(s_acc)) * 4 * RTX_BVH_WAVES <= 160 * 1024, "LDS must not bound the occupancy");
     const SceneView& sc = a.scene;
     const uint32_t tid = threadIdx.x, lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1945,34 +1853,16 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
     ps.depth = 0;
     ps.rng.state = 0;
     ps.rng.inc = 1;
-    // The query in flight.  A node group is the children of one node that the ray still has to
-    // visit: the index of the node's first inner child and (hit bits in visiting order << 24 | the
-    // node's imask); an item group the leaf slots still to test: the node and their slot bits.
-    // `order`: c = 7 - octant(ray) in its top byte (slots are visited in descending order of
-    // slot ^ c), the exchange masks of c below (exchange_slots).
-    uint32_t ng_base = 0u, ng_bits = 0u, ig_items = 0u, ig_bits = 0u, order = 0u;
+    // The query in flight: the node or leaf the lane stands at, its stack pointer, the winner so far,
+    // the ray's reciprocal direction and the ray on the tree's grid.
     uint32_t sp = 0, best = kNone;
     float closest = kFltMax;
     V3 inv = v3(0.0f, 0.0f, 0.0f), noi = inv;
-    // two-child tree: the node or leaf the lane stands at, the ray on the tree's grid
     constexpr uint32_t kDone = 0xffffffffu;
     uint32_t ref = kDone;
     BvhRay br;
     br.A = br.B = inv;
     const float fnx = (float)a.width, fny = (float)a.height;
-// the next group of this lane: from its stack, or the query is done (a macro: a lambda capturing
-// the traversal state by reference put part of it into scratch memory)
-#define RTX_NEXT_GROUP()                             \
-    do {                                             \
-        if (sp == 0u) {                              \
-            phase = kDoneWalk;                       \
-        } else {                                     \
-            --sp;                                    \
-            const uint2 e_ = s_stack[sp][tid];       \
-            ng_base = e_.x;                          \
-            ng_bits = e_.y;                          \
-        }                                            \
-    } while (0)
 
     for (;;) {
         const unsigned long long walking = rtx_ballot(phase == kWalk);
@@ -1980,8 +1870,7 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
         const unsigned long long idle = rtx_ballot(phase == kIdle);
         const bool pool_left = next < total;
         const uint32_t waiting = n_done + (pool_left ? (uint32_t)__popcll(idle) : 0u);
-        // (kLongWalks: a large two-child tree - the longer the walks, the sooner the finished lanes are shaded)
-        constexpr uint32_t kShadeBatch = kWide ? RTX_SHADE_BATCH : (kLongWalks ? RTX_SHADE_BATCH2_LONG : RTX_SHADE_BATCH2);
+        constexpr uint32_t kShadeBatch = kLongWalks ? RTX_SHADE_BATCH2_LONG : RTX_SHADE_BATCH2;
         if (waiting != 0u && (walking == 0ull || waiting >= kShadeBatch)) {
             RTX_STAT(5, 1u);      // [5] shade / refill passes of the wave
             RTX_STAT(6, n_done);  // [6] ... lanes shaded
@@ -2046,18 +1935,8 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 inv = v3(__builtin_amdgcn_fmed3f(frcp(ps.d.x), -kBig, kBig), __builtin_amdgcn_fmed3f(frcp(ps.d.y), -kBig, kBig),
                          __builtin_amdgcn_fmed3f(frcp(ps.d.z), -kBig, kBig));
                 noi = v3(-ps.o.x * inv.x, -ps.o.y * inv.y, -ps.o.z * inv.z);
-                if constexpr (kWide) {  // slots are visited in ascending order of slot ^ octant: 7 - octant in every byte
-                    const uint32_t oct = (__float_as_uint(inv.x) >> 31) | ((__float_as_uint(inv.y) >> 31) << 1) |
-                                         ((__float_as_uint(inv.z) >> 31) << 2);
-                    const uint32_t c = 7u - oct;
-                    order = (c << 24) | ((c & 1u) ? 0x55u : 0u) | ((c & 2u) ? 0x3300u : 0u) | ((c & 4u) ? 0x0f0000u : 0u);
-                    ng_base = 0u;  // the root as the one child of a group without inner-node mask: node 0
-                    ng_bits = 0x80000000u;
-                    ig_bits = 0u;
-                } else {
-                    br = bvh_ray_signed(sc, inv, noi);
-                    ref = 0u;  // root
-                }
+                br = bvh_ray_signed(sc, inv, noi);
+                ref = 0u;  // root
                 sp = 0u;
                 closest = kFltMax;
                 best = kNone;
@@ -2073,16 +1952,15 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
             continue;                  // this draw fell outside the image (ragged tile): draw again
         }
 #pragma unroll 1
-        for (int step = 0; step < (kWide ? RTX_WALK_STEPS : RTX_WALK_STEPS2); ++step) {
+        for (int step = 0; step < RTX_WALK_STEPS2; ++step) {
             RTX_STAT(4, 1u);  // [4] walk steps of the wave
-            // A lane with items left tests one; a lane without takes the next inner child of its
-            // node group one node down.  Lanes with items hold them until kLeafBatch of them have
-            // some (or nobody is left at a node), so that the leaf code - four record types, each
-            // its own branch - runs on a fuller wave.
+            // A lane at a leaf tests its record; a lane at a node goes one node down.  Lanes at a leaf
+            // hold it until kLeafBatch of them have one (or nobody is left at a node), so that the
+            // leaf code - four record types, each its own branch - runs on a fuller wave.
             // (each ballot is of ONE comparison - its condition mask is the ballot - and the masks are
             // combined on the scalar unit: the ballot of a compound condition costs two more vector
             // instructions, which turn the combined mask into 0 / 1 per lane and compare that again)
-            const bool holds_items = kWide ? ig_bits != 0u : (ref & kBvhLeaf) != 0u;
+            const bool holds_items = (ref & kBvhLeaf) != 0u;
             const bool at_leaf = phase == kWalk && holds_items;
             const bool at_node = phase == kWalk && !at_leaf;
             const unsigned long long walk_mask = rtx_ballot(phase == kWalk), item_mask = rtx_ballot(holds_items);
@@ -2096,78 +1974,37 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
                 RTX_STAT(0, 1u);                            // [0] node steps of the wave
                 RTX_STAT(1, (uint32_t)__popcll(nodes));     // [1] ... of its lanes
             }
-            constexpr uint32_t kLeafBatch = kWide ? RTX_LEAF_BATCH_WIDE : RTX_LEAF_BATCH;
+            constexpr uint32_t kLeafBatch = RTX_LEAF_BATCH;
             const bool leaves_now = n_leaves >= kLeafBatch || (nodes == 0ull && n_leaves != 0u);
             if (leaves_now) {
                 RTX_STAT(2, 1u);        // [2] item steps of the wave
                 RTX_STAT(3, n_leaves);  // [3] ... of its lanes
             }
-            if constexpr (kWide) {
-                if (at_node) {
-                    // the pending child the ray wants first: the highest hit bit
-                    const uint32_t bit = 31u - (uint32_t)__clz((int)ng_bits);
-                    ng_bits ^= 1u << bit;
-                    const uint32_t slot = (bit - 24u) ^ (order >> 24);
-                    const uint32_t node = ng_base + (uint32_t)__popc(ng_bits & ((1u << slot) - 1u));  // inner slots below it
-                    if (ng_bits & 0xff000000u) {  // siblings left: they wait on the stack
-                        s_stack[sp][tid] = make_uint2(ng_base, ng_bits);
-                        ++sp;
-                    }
-                    const uint4* p = reinterpret_cast<const uint4*>(&at32(sc.bvh_wide, node));
-                    const uint4 n0 = p[0], n2 = p[2], n3 = p[3], n4 = p[4];
-                    const uint2 bases = reinterpret_cast<const uint2*>(p)[2];  // child_base, items word
-                    const uint32_t hits = wide_node_hits(n0, n2, n3, n4, inv, noi, kTMin, closest);
-                    RTX_STAT(11, (uint32_t)__popcll(rtx_ballot(hits == 0u)));  // [11] node steps that met no child
-                    RTX_STAT(10, (uint32_t)__popcll(rtx_ballot(hits == 0u && best != kNone)));  // [10] ... with a hit in hand
-                    const uint32_t imask = n0.w >> 24;
-                    ng_base = bases.x;
-                    ng_bits = (exchange_slots(hits & imask, order) << 24) | imask;
-                    ig_items = bases.y;
-                    ig_bits = hits & ~imask;
-                    if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) RTX_NEXT_GROUP();
-                }
-                if (leaves_now && at_leaf) {
-                    // slot k's record: the node's first one + the leaf slots below k (the items word's top
-                    // byte); nothing of the node is read again
-                    const uint32_t k = (uint32_t)__ffs((int)ig_bits) - 1u;
-                    ig_bits &= ig_bits - 1u;
-                    const uint32_t first = (ig_items & kWideItemBase) + (uint32_t)__popc(__builtin_amdgcn_ubfe(ig_items, 24u, k));
-                    const uint2 top = s_stack[sp == 0u ? 0u : sp - 1u][tid];  // fetched beside the record
-                    fast_leaf_item(sc, load_fast_item(sc.wide_items, first), ps.o, ps.d, inv, noi, kTMin, closest, best);
-                    if (ig_bits == 0u && (ng_bits & 0xff000000u) == 0u) {  // as RTX_NEXT_GROUP
-                        if (sp == 0u) phase = kDoneWalk;
-                        ng_base = sp != 0u ? top.x : ng_base;
-                        ng_bits = sp != 0u ? top.y : ng_bits;
-                        sp -= sp != 0u ? 1u : 0u;
-                    }
-                }
-            } else {
-                if (at_node) {
-                    // Without branches: the top of the stack is fetched beside the node whether or not this
-                    // step pops it, and the farther child is written above the top whether or not both
-                    // children are met (sp only moves past it if they are; rtx_upload_scene refuses a tree
-                    // deeper than the stack, so that row exists).
-                    const uint32_t below = s_stack2[sp == 0u ? 0u : sp - 1u][tid];
-                    const NodeWords N = load_node(sc, ref);
-                    float n0, n1;
-                    const bool h0 = slab_signed(N.a.x, N.a.y, N.a.z, br, kTMin, closest, n0);
-                    const bool h1 = slab_signed(N.a.w, N.b.x, N.b.y, br, kTMin, closest, n1);
-                    const bool both = h0 && h1, any = h0 || h1;
-                    const bool take0 = h0 && (!h1 || n0 <= n1);  // the nearer child first
-                    s_stack2[sp][tid] = take0 ? N.b.w : N.b.z;
-                    const bool pop = !any && sp != 0u;
-                    ref = any ? (take0 ? N.b.z : N.b.w) : (sp != 0u ? below : kDone);
-                    sp = sp + (both ? 1u : 0u) - (pop ? 1u : 0u);
-                    if (ref == kDone) phase = kDoneWalk;
-                }
-                if (leaves_now && at_leaf) {
-                    // (a leaf of this tree is one record: rtx_bvh.cpp builds it with kLeafItems = 1)
-                    const uint32_t below = s_stack2[sp == 0u ? 0u : sp - 1u][tid];  // fetched beside the record
-                    fast_leaf_item(sc, load_fast_item(sc.bvh_fast, ref & kBvhLeafFirst), ps.o, ps.d, inv, noi, kTMin, closest, best);
-                    ref = sp != 0u ? below : kDone;
-                    sp -= sp != 0u ? 1u : 0u;
-                    if (ref == kDone) phase = kDoneWalk;
-                }
+            if (at_node) {
+                // Without branches: the top of the stack is fetched beside the node whether or not this
+                // step pops it, and the farther child is written above the top whether or not both
+                // children are met (sp only moves past it if they are; rtx_upload_scene refuses a tree
+                // deeper than the stack, so that row exists).
+                const uint32_t below = s_stack2[sp == 0u ? 0u : sp - 1u][tid];
+                const NodeWords N = load_node(sc, ref);
+                float n0, n1;
+                const bool h0 = slab_signed(N.a.x, N.a.y, N.a.z, br, kTMin, closest, n0);
+                const bool h1 = slab_signed(N.a.w, N.b.x, N.b.y, br, kTMin, closest, n1);
+                const bool both = h0 && h1, any = h0 || h1;
+                const bool take0 = h0 && (!h1 || n0 <= n1);  // the nearer child first
+                s_stack2[sp][tid] = take0 ? N.b.w : N.b.z;
+                const bool pop = !any && sp != 0u;
+                ref = any ? (take0 ? N.b.z : N.b.w) : (sp != 0u ? below : kDone);
+                sp = sp + (both ? 1u : 0u) - (pop ? 1u : 0u);
+                if (ref == kDone) phase = kDoneWalk;
+            }
+            if (leaves_now && at_leaf) {
+                // (a leaf of this tree is one record: rtx_bvh.cpp builds it with kLeafItems = 1)
+                const uint32_t below = s_stack2[sp == 0u ? 0u : sp - 1u][tid];  // fetched beside the record
+                fast_leaf_item(sc, load_fast_item(sc.bvh_fast, ref & kBvhLeafFirst), ps.o, ps.d, inv, noi, kTMin, closest, best);
+                ref = sp != 0u ? below : kDone;
+                sp -= sp != 0u ? 1u : 0u;
+                if (ref == kDone) phase = kDoneWalk;
             }
         }
     }
@@ -2198,7 +2035,6 @@ __global__ void __launch_bounds__(RTX_BVH_BLOCK, RTX_BVH_WAVES) trace_bvh_kernel
 #endif
     }
 }
-#undef RTX_NEXT_GROUP
 #undef RTX_STAT
 #endif
 

@@ -158,42 +158,12 @@ struct alignas(32) BvhNode {
 };
 // Entries of the traversal's per-lane stack: one deferred child per level, so a tree may be at
 // most kBvhStackEntries - 1 levels deep (the builder bounds it, the upload checks it).  The fast
-// BVH trace kernel's occupancy hangs on this number and on kWideStackEntries: 256 bytes of LDS per
-// wave and entry, 5.5 KB per wave as they stand, and 6 KB would cost it two resident waves per CU.
+// BVH trace kernel's occupancy hangs on this number: 256 bytes of LDS per wave and entry, 5.5 KB
+// per wave as it stands, and 6 KB would cost it two resident waves per CU.
 constexpr int kBvhStackEntries = 22;
 constexpr uint32_t kBvhLeaf = 0x80000000u;
 constexpr uint32_t kBvhLeafFirst = 0x07ffffffu;
 constexpr uint32_t kBvhLeafCountShift = 27u;
-
-// Eight-wide tree for the fast-mode trace kernel (the two-child tree collapsed three levels at a
-// time).  Traversal of incoherent rays is bound by the chain of dependent node fetches, so a
-// node decides eight subtrees per fetch: 80 bytes = five 16-byte loads.  The children's boxes are
-// 8-bit coordinates on the node's own grid p + q * 2^e (per axis; rounded outwards), decoded
-// inside the slab test's fused multiply-adds.  Children that are inner nodes lie consecutively
-// from `child_base` in slot order; children that are leaves hold one record of `wide_items`
-// each, consecutive in slot order from `items & kWideItemBase`, and bits 24..31 of `items` say
-// which slots are leaves: slot k's record is the base + the leaf slots below k, known without
-// another look at the node.  `meta` (0 empty, 0x20 | (24 + slot) inner node, 0x20 | offset of
-// the record from the base for a leaf) restates that per slot for host-side checks.  Slots are
-// assigned so that slot bit a set means "towards +axis a" within the node: a ray visits the
-// slots in ascending order of slot ^ octant(ray), which is roughly front to back and needs no
-// sorting.  (Layout after Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal on GPUs
-// Through Compressed Wide BVHs", 2017.)
-struct alignas(16) WideNode {
-    float p[3];
-    uint8_t e[3];       // biased fp32 exponent of the grid step per axis
-    uint8_t imask;      // bit s: slot s holds an inner node
-    uint32_t child_base;
-    uint32_t items;     // first leaf record | leaf slots << 24
-    uint8_t meta[8];
-    uint8_t qlo[3][8];  // [axis][slot]
-    uint8_t qhi[3][8];
-};
-static_assert(sizeof(WideNode) == 80, "five 16-byte loads");
-// Entries of the wide traversal's per-lane stack (8 bytes each): one per level that still has
-// unvisited children.  Deeper trees are rendered through the two-child tree instead.
-constexpr int kWideStackEntries = 11;
-constexpr uint32_t kWideItemBase = 0x00ffffffu;  // a wide tree holds fewer than 2^24 leaf records
 
 // Fast-mode leaf record, one per BVH item in leaf order, so that a leaf costs one 32-byte
 // fetch instead of the chain item -> steps -> primitive:
@@ -238,8 +208,6 @@ struct SceneView {
                                // then the n_bvh_big groups outside the tree that every ray tests
     const BvhFastItem* bvh_fast;  // the same items as fast-mode leaf records
     const BvhMap* bvh_maps;       // affine maps of the box / group records
-    const WideNode* bvh_wide;        // eight-wide tree (null: not built or too deep for its stack)
-    const BvhFastItem* wide_items;   // leaf records in the wide tree's item order
     float bvh_origin[3], bvh_scale[3];  // the grid of the nodes' 16-bit boxes
     uint32_t bvh_big_first, n_bvh_big;
     uint32_t n_prims, n_groups, n_steps, n_materials, n_textures, n_lights, n_bvh_nodes;

@@ -237,126 +237,10 @@ int main(int argc, char** argv) {
         }
     }
 
-    // ---- eight-wide tree: the same leaves, reached by the device's walk (slots visited in
-    // ascending slot ^ octant order through node groups, one stack entry per level) ----
-    if (tree.wide.empty()) return fail("no wide nodes");
-    if (tree.wide_order.size() != n_tree_items) return fail("wide tree: item order does not cover the in-tree items");
-    {
-        std::vector<int> ordered(n_tree_items, 0);
-        for (uint32_t k : tree.wide_order) {
-            if (k >= n_tree_items) return fail("wide tree: item out of range");
-            ++ordered[k];
-        }
-        for (int c : ordered)
-            if (c != 1) return fail("wide tree: an item is not in the order exactly once");
-        // structure: inner children consecutive from child_base, items from item_base, every
-        // node referenced once, child boxes decoded on the node's grid contain the exact bounds
-        std::vector<int> node_seen(tree.wide.size(), 0), item_seen(n_tree_items, 0);
-        node_seen[0] = 1;
-        for (size_t i = 0; i < tree.wide.size(); ++i) {
-            const rtxd::WideNode& W = tree.wide[i];
-            uint32_t rel = 0;
-            for (int sidx = 0; sidx < 8; ++sidx) {
-                const uint32_t meta = W.meta[sidx];
-                const bool inner = (W.imask >> sidx) & 1u;
-                if ((inner || meta == 0u) && ((W.items >> (24 + sidx)) & 1u)) return fail("wide tree: items word marks a slot that is no leaf");
-                if (inner) {
-                    if (meta != (0x20u | (24u + (uint32_t)sidx))) return fail("wide tree: inner slot meta");
-                    const uint32_t c = W.child_base + rel++;
-                    if (c >= tree.wide.size() || c <= i) return fail("wide tree: child index");
-                    ++node_seen[c];
-                } else if (meta != 0u) {
-                    const uint32_t unary = meta >> 5, offset = meta & 31u;
-                    // the device finds the record by counting the leaf slots below this one
-                    const uint32_t leaf_slots = W.items >> 24;
-                    if (!((leaf_slots >> sidx) & 1u)) return fail("wide tree: leaf slot missing from the items word");
-                    if (offset != (uint32_t)__builtin_popcount(leaf_slots & ((1u << sidx) - 1u)) || unary != 1u)
-                        return fail("wide tree: leaf record is not at its slot's rank");
-                    const uint32_t count = unary == 1u ? 1u : (unary == 3u ? 2u : (unary == 7u ? 3u : 99u));
-                    if (count == 99u || offset + count > 24u) return fail("wide tree: leaf slot meta");
-                    for (uint32_t k = 0; k < count; ++k) {
-                        if ((W.items & rtxd::kWideItemBase) + offset + k >= n_tree_items) return fail("wide tree: leaf item out of range");
-                        ++item_seen[(W.items & rtxd::kWideItemBase) + offset + k];
-                    }
-                }
-            }
-        }
-        for (int c : node_seen)
-            if (c != 1) return fail("wide tree: a node is not referenced exactly once");
-        for (int c : item_seen)
-            if (c != 1) return fail("wide tree: an item is not in exactly one leaf");
-        if (tree.wide_depth < 1 || tree.wide_depth > max_depth + 1) return fail("wide tree: depth");
-    }
-    uint32_t wchecked = 0, wvisited = 0;
-    int wstack_max = 0;
-    for (int r = 0; r < 400; ++r) {
-        const double o[3] = {100.0 * U(gen), 10.0 * U(gen) + 5.0, 100.0 * U(gen)};
-        double d[3] = {D(gen), D(gen), D(gen)};
-        if (r % 2 == 0) {
-            const Box3& b = exact[gen() % groups.size()];
-            for (int a = 0; a < 3; ++a) d[a] = 0.5 * (b.lo[a] + b.hi[a]) - o[a];
-        }
-        if (r % 7 == 0) d[r % 3] = 0.0;
-        const uint32_t oct = (d[0] < 0 ? 1u : 0u) | (d[1] < 0 ? 2u : 0u) | (d[2] < 0 ? 4u : 0u), oct_inv = 7u - oct;
-        std::vector<int> reached(n_tree_items, 0);
-        struct Group2 { uint32_t base, bits; };
-        std::vector<Group2> st;
-        Group2 ng{0u, 0x80000000u};
-        for (;;) {
-            if (!(ng.bits & 0xff000000u)) {
-                if (st.empty()) break;
-                ng = st.back();
-                st.pop_back();
-                continue;
-            }
-            uint32_t bit = 31u;
-            while (!((ng.bits >> bit) & 1u)) --bit;
-            ng.bits &= ~(1u << bit);
-            const uint32_t slot = (bit - 24u) ^ oct_inv;
-            uint32_t rel = 0;
-            for (uint32_t b = 0; b < slot; ++b) rel += (ng.bits >> b) & 1u;
-            const uint32_t node = ng.base + rel;
-            if (ng.bits & 0xff000000u) st.push_back(ng);
-            wstack_max = std::max(wstack_max, (int)st.size());
-            if (node >= tree.wide.size()) return fail("wide walk: node out of range");
-            const rtxd::WideNode& W = tree.wide[node];
-            ++wvisited;
-            uint32_t hitmask = 0;
-            for (uint32_t sidx = 0; sidx < 8; ++sidx) {
-                if (W.meta[sidx] == 0u) continue;
-                double lo[3], hi[3];
-                for (int a = 0; a < 3; ++a) {
-                    const double step = std::ldexp(1.0, (int)W.e[a] - 127);
-                    lo[a] = (double)W.p[a] + W.qlo[a][sidx] * step;
-                    hi[a] = (double)W.p[a] + W.qhi[a][sidx] * step;
-                }
-                if (!ray_box(o, d, lo, hi)) continue;
-                const uint32_t meta = W.meta[sidx];
-                const bool inner = (W.imask >> sidx) & 1u;
-                const uint32_t index = inner ? ((meta & 31u) ^ oct_inv) : (meta & 31u);  // 24 + (slot ^ oct_inv)
-                hitmask |= (meta >> 5) << index;
-            }
-            for (uint32_t b = 0; b < 24u; ++b)
-                if ((hitmask >> b) & 1u) reached[(W.items & rtxd::kWideItemBase) + b] = 1;
-            ng.base = W.child_base;
-            ng.bits = (hitmask & 0xff000000u) | W.imask;
-        }
-        for (uint32_t k = 0; k < n_tree_items; ++k) {
-            const Box3& b = exact[item_group[tree.wide_order[k]]];
-            if (ray_box(o, d, b.lo, b.hi)) {
-                ++wchecked;
-                if (!reached[k]) return fail("wide walk: a ray meets an item's bounds but its leaf is not reached");
-            }
-        }
-    }
-    if (wstack_max > tree.wide_depth) return fail("wide walk: stack deeper than the tree");
-    std::printf("wide nodes=%zu depth=%d stack max=%d pairs=%u visited/ray=%.1f\n", tree.wide.size(), tree.wide_depth,
-                wstack_max, wchecked, wvisited / 400.0);
-    // the builder's surface-area estimates, which the upload uses to choose between the two trees: the
-    // root counts once in both, and collapsing a tree cannot add visits
-    if (tree.nodes.size() > 1 && !(tree.visits_wide >= 1.0 - 1e-9 && tree.visits_two_child >= tree.visits_wide - 1e-9))
-        return fail("visit estimates: expected 1 <= wide <= two-child");
-    std::printf("estimated visits two-child=%.2f wide=%.2f\n", tree.visits_two_child, tree.visits_wide);
+    // the builder's surface-area estimate of the inner nodes a ray through the root box visits: the
+    // root counts once
+    if (tree.nodes.size() > 1 && !(tree.visits >= 1.0 - 1e-9)) return fail("visit estimate: expected >= 1");
+    std::printf("estimated visits=%.2f\n", tree.visits);
 
     // ---- light tree: every group as a light leaf, entries = arbitrary distinct numbers ----
     std::vector<uint32_t> entries(groups.size());

@@ -29,7 +29,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(api.RtxParams) == 40
     assert ctypes.sizeof(api.RtxHit) == 48
     assert api.HIT_DTYPE.itemsize == 48
-    assert ctypes.sizeof(api.RtxSceneInfo) == 16
+    assert ctypes.sizeof(api.RtxSceneInfo) == 24
     assert api.RtxScene.cam_origin.offset % 4 == 0
 
 
