@@ -15,12 +15,14 @@
  * radiance.  The random stream is the counter-based one of include/rtx_det.h,
  * substituted for rand() by oracle/ref_shim.h.
  */
-#define private public /* reach Scene::m_world / m_light / m_camera / m_backColor (Scene.h:37-43) */
+#define private public /* reach Scene::m_world / m_light / m_camera / m_backColor (Scene.h:37-43) and, for
+                          the general light shapes below, what the shape classes hold (Rect.h:31-33,
+                          Translate.h:15-16, Rotate.h:15-16, FlipNormals.h:14, Box.h:14-15, ShapeList.h:19) */
 #include "Scene.h"
-#undef private
-
 #include "ShapeList.h"
 #include "ShapeBuilder.h"
+#undef private
+
 #include "HitRec.h"
 #include "ScatterRec.h"
 #include "Lambertian.h"
@@ -47,6 +49,93 @@ private:
     Vector3 m_centre;
     Scene m_scene;
 };
+
+// General light shapes.  In the reference only an XZ rect and a sphere can be sampled as lights:
+// Rect::pdf_value / random give up on the other two axes (Rect.cpp:37,51) and FlipNormals, Translate,
+// Rotate and Box keep Shape's defaults, 0 and (1,0,0) (Shape.h:8-9).  The renderer's opt-in general
+// light sampling (RTX_LIGHTS_GENERAL) gives all of them a density.  These classes state the same
+// extension against the reference's Shape interface, so that a light shape built from them runs
+// through the UNMODIFIED Scene::color -> MixturePdf -> ShapePdf -> ShapeList::pdf_value / random
+// (Scene.cpp:112-120, MixturePdf.h:7-22, ShapePdf.h:8-17, ShapeList.cpp:19-35): the mixture, the
+// list weights, the draw order and the integrator are the reference's, only the leaf densities
+// and the way a query passes a wrapper are the extension's.
+class GeneralRect : public Shape {  // a rect of any axis, sampled by area like the XZ one
+public:
+    explicit GeneralRect(const Rect& r) : m_rect(r) {}
+    bool hit(const Ray& r, float t0, float t1, HitRec& hrec) const override { return m_rect.hit(r, t0, t1, hrec); }
+    float pdf_value(const Vector3& o, const Vector3& v) const override {  // Rect.cpp:38-47 for the rect's own axis
+        HitRec hrec;
+        if (!m_rect.hit(Ray(o, v), 0.001f, FLT_MAX, hrec)) return 0;
+        const float area = (m_rect.m_x1 - m_rect.m_x0) * (m_rect.m_y1 - m_rect.m_y0);
+        const float distance_squared = pow2(hrec.t) * lengthSqr(v);
+        const float cosine = fabs(dot(v, hrec.n)) / length(v);
+        return distance_squared / (cosine * area);
+    }
+    Vector3 random(const Vector3& o) const override {  // Rect.cpp:52-67 for the rect's own axis
+        const float x = m_rect.m_x0 + drand48() * (m_rect.m_x1 - m_rect.m_x0);
+        const float y = m_rect.m_y0 + drand48() * (m_rect.m_y1 - m_rect.m_y0);
+        const float k = m_rect.m_k;
+        const Vector3 point = m_rect.m_axis == Rect::kXY ? Vector3(x, y, k)
+                            : m_rect.m_axis == Rect::kXZ ? Vector3(x, k, y) : Vector3(k, x, y);
+        return point - o;
+    }
+
+private:
+    Rect m_rect;
+};
+class LightFlip : public Shape {  // FlipNormals: the densities use |cos|, a flip changes nothing
+public:
+    explicit LightFlip(const ShapePtr& s) : m_shape(s) {}
+    bool hit(const Ray& r, float t0, float t1, HitRec& hrec) const override { return m_shape->hit(r, t0, t1, hrec); }
+    float pdf_value(const Vector3& o, const Vector3& v) const override { return m_shape->pdf_value(o, v); }
+    Vector3 random(const Vector3& o) const override { return m_shape->random(o); }
+
+private:
+    ShapePtr m_shape;
+};
+class LightTranslate : public Shape {  // the query enters the frame as a ray enters Translate::hit (Translate.cpp:7)
+public:
+    LightTranslate(const ShapePtr& s, const Vector3& offset) : m_shape(s), m_offset(offset) {}
+    bool hit(const Ray& r, float t0, float t1, HitRec& hrec) const override { return false; }
+    float pdf_value(const Vector3& o, const Vector3& v) const override { return m_shape->pdf_value(o - m_offset, v); }
+    Vector3 random(const Vector3& o) const override { return m_shape->random(o - m_offset); }
+
+private:
+    ShapePtr m_shape;
+    Vector3 m_offset;
+};
+class LightRotate : public Shape {  // ... and Rotate::hit (Rotate.cpp:7-9); a direction leaves as a normal does (Rotate.cpp:13)
+public:
+    LightRotate(const ShapePtr& s, const Quat& q) : m_shape(s), m_quat(q) {}
+    bool hit(const Ray& r, float t0, float t1, HitRec& hrec) const override { return false; }
+    float pdf_value(const Vector3& o, const Vector3& v) const override {
+        const Quat revq = conj(m_quat);
+        return m_shape->pdf_value(rotate(revq, o), rotate(revq, v));
+    }
+    Vector3 random(const Vector3& o) const override { return rotate(m_quat, m_shape->random(rotate(conj(m_quat), o))); }
+
+private:
+    ShapePtr m_shape;
+    Quat m_quat;
+};
+// The general counterpart of a light shape built through the reference's ShapeBuilder: a Box
+// becomes the list of its faces (the reference's own ShapeList, so one more draw picks the face
+// and each face weighs 1/6), a sphere stays the reference's Sphere.
+static ShapePtr general_light(const ShapePtr& s) {
+    if (const Rect* r = dynamic_cast<const Rect*>(s.get())) return std::make_shared<GeneralRect>(*r);
+    if (const FlipNormals* f = dynamic_cast<const FlipNormals*>(s.get())) return std::make_shared<LightFlip>(general_light(f->m_shape));
+    if (const Translate* t = dynamic_cast<const Translate*>(s.get()))
+        return std::make_shared<LightTranslate>(general_light(t->m_shape), t->m_offset);
+    if (const Rotate* r = dynamic_cast<const Rotate*>(s.get())) return std::make_shared<LightRotate>(general_light(r->m_shape), r->m_quat);
+    const ShapeList* list = dynamic_cast<const ShapeList*>(s.get());
+    if (const Box* b = dynamic_cast<const Box*>(s.get())) list = b->m_list.get();
+    if (list) {
+        auto out = std::make_shared<ShapeList>();
+        for (const ShapePtr& c : list->m_list) out->add(general_light(c));
+        return out;
+    }
+    return s;
+}
 
 // internal linkage: the renderer's host library includes the same file against its own classes
 namespace {
@@ -114,7 +203,7 @@ void* ref_scene_create(const char* name, int w, int h) {
     } else {
         SceneParts parts;
         if (!make_scene(name, w, h, parts)) return nullptr;
-        if (parts.sky || !parts.light || parts.general_lights) {  // the reference's color() cannot render these
+        if (parts.sky || !parts.light) {  // the reference's color() cannot render these
             delete parts.camera;
             delete parts.world;
             delete parts.light;
@@ -123,6 +212,11 @@ void* ref_scene_create(const char* name, int w, int h) {
         rs->own_camera.reset(parts.camera);
         rs->own_world.reset(parts.world);
         rs->own_light.reset(parts.light);
+        if (parts.general_lights) {  // the same light list made of the general shapes above
+            auto general = std::make_unique<ShapeList>();
+            for (const ShapePtr& c : parts.light->m_list) general->add(general_light(c));
+            rs->own_light = std::move(general);
+        }
         rs->scene->m_backColor = parts.background;
         rs->world = rs->own_world.get();
         rs->light = rs->own_light.get();

@@ -37,16 +37,18 @@ SAMPLE_CASES = [  # scene, w, h, spp_begin, spp, seed
     ("sky_spheres", 48, 27, 0, 8, 7),  # no light shape + sky: from the CPU restatement (see RESTATEMENT_ONLY)
     ("sky_sphere_lit", 48, 27, 0, 8, 7),  # the sky gradient as an emitting sphere around the scene: the REFERENCE renders it
     ("cornell_light_tree", 48, 27, 0, 8, 7),   # nested light lists, XY rect / wrapped shapes with the default density
-    ("cornell_side_lights", 48, 27, 0, 8, 7),  # general light sampling: from the CPU restatement
+    ("cornell_side_lights", 48, 27, 0, 8, 7),  # general light sampling: the reference's integrator over the driver's general light shapes
     ("cornell_many_lights", 48, 27, 0, 8, 7),  # a flat list of 40 lights
     ("cornell_many_lights_10", 40, 22, 0, 4, 7),  # 104 lights: the GPU sums their densities through a tree
 ]
 # Scenes the reference's color() cannot render (it dereferences its light, Scene.cpp:113, and
 # never calls backgroundSky): their vectors come from oracle/restate.cpp, whose pieces for this
 # mode are pinned against the reference function by function (sky_and_cosine_pdf.npz).
-# Likewise general light sampling (XY / YZ rect, flipped / rotated / translated lights, a box):
-# the reference gives these shapes density 0 and direction (1,0,0) (Rect.cpp:37,51, Shape.h:8-9).
-RESTATEMENT_ONLY = ("sky_spheres", "cornell_side_lights")
+# General light sampling (XY / YZ rect, flipped / rotated / translated lights, a box: the reference
+# gives these shapes density 0 and direction (1,0,0), Rect.cpp:37,51, Shape.h:8-9) does run through
+# the reference's color(): oracle/ref_driver.cpp states the leaf densities as Shape subclasses, and
+# the mixture, the list weights, the draw order and the integrator are the reference's own.
+RESTATEMENT_ONLY = ("sky_spheres",)
 HIT_SCENES = ("cornell", "cornell_extra", "random_field", "bvh_stress_500", "textured")  # + sky_spheres needs no hits: same shapes
 TEXTURE = os.path.join(HERE, "texture_64x32.bmp")
 
@@ -184,7 +186,7 @@ def jpeg_vectors():
     np.savez_compressed(os.path.join(HERE, "jpeg_cases.npz"), **out)
 
 
-LIGHT_SCENES = ("cornell", "small", "cornell_light_tree", "cornell_many_lights")
+LIGHT_SCENES = ("cornell", "small", "cornell_light_tree", "cornell_many_lights", "cornell_side_lights")
 
 
 def light_queries(name, n, rng):

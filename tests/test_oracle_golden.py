@@ -86,9 +86,11 @@ def test_restatement_sky_and_cosine_pdf_match_reference():
 def test_restatement_light_shape_density_and_sampling_match_reference():
     """Shape::pdf_value / Shape::random of whole light shapes (ShapeList.cpp:19-35, Rect.cpp:36-68,
     Sphere.cpp:38-58, Shape.h:8-9), function by function: a flat list, one sphere, nested lists
-    with shapes of the default density, a list of 40 lights."""
+    with shapes of the default density, a list of 40 lights; and, for general light sampling, the
+    reference's ShapeList over the general light shapes of oracle/ref_driver.cpp (a flipped YZ rect,
+    a flipped XY rect, a rotated and translated box as the list of its faces)."""
     g = util.load_golden("light_pdf")
-    for name in ("cornell", "small", "cornell_light_tree", "cornell_many_lights"):
+    for name in ("cornell", "small", "cornell_light_tree", "cornell_many_lights", "cornell_side_lights"):
         scene = api.HostScene(name, 32, 32)
         vals, dirs = restate.light_pdf(scene, g[name + "_o"], g[name + "_v"], seed=int(g["seed"]))
         assert np.array_equal(vals, g[name + "_values"], equal_nan=True), name
@@ -98,8 +100,10 @@ def test_restatement_light_shape_density_and_sampling_match_reference():
 
 def test_restatement_general_light_sampling_is_unbiased():
     """General light sampling (rects of every axis, rotated / translated / boxed lights) is an
-    extension the reference cannot check: its own contract is that it leaves the expectation of
-    the estimator alone.  Against the same scene rendered with the material's pdf only."""
+    extension of the reference's leaf densities (its paths are pinned sample for sample through the
+    reference's own integrator, see the golden "samples_cornell_side_lights"); what the extension
+    itself owes is that it leaves the expectation of the estimator alone.  Against the same scene
+    rendered with the material's pdf only."""
     w, h = 64, 36
     lit = restate.render(api.HostScene("cornell_side_lights", w, h), w, h, 0, 1024, seed=1, threads=8)["sum"] / 1024
     unlit = restate.render(api.HostScene("cornell_side_lights_nolight", w, h), w, h, 0, 4096, seed=2, threads=8)["sum"] / 4096
@@ -168,7 +172,7 @@ def test_builtin_scene_equals_transcribed_scene():
 def test_reference_and_restatement_agree_on_fresh_inputs():
     for name, w, h, spp, seed in (("cornell_extra", 36, 20, 6, 1234), ("random_field", 30, 16, 3, 99),
                                   ("textured", 40, 22, 5, 31), ("cornell_light_tree", 40, 22, 6, 5),
-                                  ("cornell_many_lights", 40, 22, 6, 5)):
+                                  ("cornell_many_lights", 40, 22, 6, 5), ("cornell_side_lights", 40, 22, 6, 5)):
         scene = api.HostScene(name, w, h)
         a = restate.render(scene, w, h, 10, spp, seed=seed, threads=4, per_sample=True)
         b = ref.RefScene(name, w, h).render(10, spp, seed=seed, threads=4, per_sample=True)
@@ -178,7 +182,7 @@ def test_reference_and_restatement_agree_on_fresh_inputs():
 @needs_ref
 def test_light_shape_golden_is_what_the_reference_returns():
     g = util.load_golden("light_pdf")
-    for name in ("cornell", "cornell_many_lights"):
+    for name in ("cornell", "cornell_many_lights", "cornell_side_lights"):
         vals, dirs = ref.RefScene(name, 32, 32).light_pdf(g[name + "_o"], g[name + "_v"], seed=int(g["seed"]))
         assert np.array_equal(vals, g[name + "_values"], equal_nan=True)
         assert np.array_equal(dirs, g[name + "_dirs"], equal_nan=True)

@@ -56,6 +56,10 @@ def _compare_samples(got_rgb, got_seg, want_rgb, want_seg):
     ("cornell_many_lights", 64, 36, 8, api.RTX_ACCEL_LINEAR),  # 40 lights in a flat list: the plain density sum
     ("cornell_many_lights_10", 48, 27, 6, api.RTX_ACCEL_LINEAR),  # 104 lights: the density sum walks the light tree
     ("cornell_many_lights_10", 48, 27, 6, api.RTX_ACCEL_BVH),
+    # general light sampling: the reference's integrator, mixture and list over the general light
+    # shapes of oracle/ref_driver.cpp (flipped YZ / XY rects, a rotated and translated box)
+    ("cornell_side_lights", 64, 36, 8, api.RTX_ACCEL_LINEAR),
+    ("cornell_side_lights", 64, 36, 8, api.RTX_ACCEL_BVH),
 ])
 def test_deterministic_samples_match_reference(gpu_ctx, name, w, h, spp, accel):
     ref = _ref()
