@@ -132,6 +132,12 @@ struct BvhNodeCpu {
 struct Bvh {
     std::vector<BvhItem> items;
     std::vector<BvhNodeCpu> nodes;
+    // A tree handed in from outside (restate_set_external_tree: the renderer's own builder, exported
+    // by tests/tree_export.cpp) is walked the way the GPU kernel walks it: both children of a node
+    // tested on arrival, the nearer one first, the farther one deferred; the last n_big items lie
+    // outside the tree and are tested first by every ray.
+    bool two_child_order = false;
+    int n_big = 0;
 };
 
 void quat_rotate_d(const double q[4], double v[3]) {  // quat_aos.h:400-412 in double
@@ -254,6 +260,7 @@ public:
     Tracer(const RtxScene& s, int max_depth, const Bvh* bvh = nullptr) : sc(s), m_max_depth(max_depth), m_bvh(bvh) {}
     RtxRng rng{0u, 1u};
     unsigned long long segments = 0;
+    unsigned long long tree_nodes = 0;  // inner nodes visited by world_hit_tree
 
     F draw() { return F(rtx_rng_nextf(&rng)); }  // drand48(), Util.h:10-12
 
@@ -297,6 +304,7 @@ public:
     // inside the run is carried back out once (Rotate.cpp:12-13, Translate.cpp:9).
     bool world_hit(const Vec<F>& o, const Vec<F>& d, F t0, F t1, Hit<F>& rec) {
         ++segments;
+        if (m_bvh && m_bvh->two_child_order) return world_hit_tree(o, d, t0, t1, rec);
         if (m_bvh) return world_hit_bvh(o, d, t0, t1, rec);
         F closest = t1;
         bool any = false;
@@ -385,68 +393,125 @@ public:
                 stack[sp++] = N.right;
                 continue;
             }
-            for (int k = N.first; k < N.first + N.count; ++k) {
-                const BvhItem& it = m_bvh->items[k];
-                const uint32_t chain = sc.prim_chain[it.prim_begin];
-                const uint32_t sb = sc.chain_begin[chain], se = sc.chain_begin[chain + 1];
-                Vec<F> ro = o, rd = d;
-                for (uint32_t s = sb; s < se; ++s) {  // Translate.cpp:7, Rotate.cpp:7-9
-                    if (sc.step_kind[s] == RTX_STEP_TRANSLATE) {
-                        ro = ro - Vec<F>(sc.step_x[s], sc.step_y[s], sc.step_z[s]);
-                    } else {
-                        F qx = -sc.step_x[s], qy = -sc.step_y[s], qz = -sc.step_z[s], qw = sc.step_w[s];
-                        ro = rotate(qx, qy, qz, qw, ro);
-                        rd = rotate(qx, qy, qz, qw, rd);
-                    }
+            for (int k = N.first; k < N.first + N.count; ++k)
+                test_item(m_bvh->items[k], o, d, t0, t1, closest, any, best_is_rect, rec);
+        }
+        return any;
+    }
+
+    // One item of a hierarchy (a bare primitive, or a run of primitives under one transform chain)
+    // against the ray: the body of ShapeList::hit's loop for those primitives, with ties between
+    // equal distances resolved by the list-order rule stated above the hierarchy.
+    void test_item(const BvhItem& it, const Vec<F>& o, const Vec<F>& d, F t0, F t1, F& closest, bool& any, bool& best_is_rect,
+                   Hit<F>& rec) {
+        const uint32_t chain = sc.prim_chain[it.prim_begin];
+        const uint32_t sb = sc.chain_begin[chain], se = sc.chain_begin[chain + 1];
+        Vec<F> ro = o, rd = d;
+        for (uint32_t s = sb; s < se; ++s) {  // Translate.cpp:7, Rotate.cpp:7-9
+            if (sc.step_kind[s] == RTX_STEP_TRANSLATE) {
+                ro = ro - Vec<F>(sc.step_x[s], sc.step_y[s], sc.step_z[s]);
+            } else {
+                F qx = -sc.step_x[s], qy = -sc.step_y[s], qz = -sc.step_z[s], qw = sc.step_w[s];
+                ro = rotate(qx, qy, qz, qw, ro);
+                rd = rotate(qx, qy, qz, qw, rd);
+            }
+        }
+        for (uint32_t p = it.prim_begin; p < it.prim_end; ++p) {
+            const uint32_t kind = sc.prim_kind[p];
+            const bool is_rect = kind != RTX_PRIM_SPHERE;
+            F t;
+            bool ok;
+            // the primitive's own candidate: the upper end of the window is open for a
+            // sphere and closed for a rect, exactly as when it is the scan's current t1
+            if (is_rect)
+                ok = rect_hit(kind, sc.prim_a[p], sc.prim_b[p], sc.prim_c[p], sc.prim_d[p], sc.prim_e[p], ro, rd, t0, closest, t);
+            else
+                ok = sphere_hit(Vec<F>(sc.prim_a[p], sc.prim_b[p], sc.prim_c[p]), F(sc.prim_d[p]), ro, rd, t0, t1, t) &&
+                     !(t > closest);
+            if (!ok) continue;
+            bool take = !any || t < closest;
+            if (!take) {  // tie with the current winner
+                const uint32_t cur = (uint32_t)rec.prim;
+                if (is_rect && best_is_rect) take = p > cur;
+                else if (is_rect != best_is_rect) take = is_rect;
+                else take = p < cur;
+            }
+            if (!take) continue;
+            closest = t;
+            any = true;
+            best_is_rect = is_rect;
+            Hit<F> local;
+            local.t = t;
+            local.p = ro + rd * t;
+            if (!is_rect)
+                local.n = (local.p - Vec<F>(sc.prim_a[p], sc.prim_b[p], sc.prim_c[p])) / F(sc.prim_d[p]);
+            else
+                local.n = Vec<F>(kind == RTX_PRIM_RECT_YZ ? 1.0f : 0.0f, kind == RTX_PRIM_RECT_XZ ? 1.0f : 0.0f,
+                                 kind == RTX_PRIM_RECT_XY ? 1.0f : 0.0f);
+            fill_uv(p, kind, ro, rd, t, local);
+            if (sc.prim_flip[p]) local.n = -local.n;
+            local.prim = (int)p;
+            local.material = sc.prim_material[p];
+            for (uint32_t s = se; s > sb; --s) {  // Rotate.cpp:12-13, Translate.cpp:9
+                const uint32_t q = s - 1;
+                if (sc.step_kind[q] == RTX_STEP_TRANSLATE) {
+                    local.p = local.p + Vec<F>(sc.step_x[q], sc.step_y[q], sc.step_z[q]);
+                } else {
+                    F qx = sc.step_x[q], qy = sc.step_y[q], qz = sc.step_z[q], qw = sc.step_w[q];
+                    local.p = rotate(qx, qy, qz, qw, local.p);
+                    local.n = rotate(qx, qy, qz, qw, local.n);
                 }
-                for (uint32_t p = it.prim_begin; p < it.prim_end; ++p) {
-                    const uint32_t kind = sc.prim_kind[p];
-                    const bool is_rect = kind != RTX_PRIM_SPHERE;
-                    F t;
-                    bool ok;
-                    // the primitive's own candidate: the upper end of the window is open for a
-                    // sphere and closed for a rect, exactly as when it is the scan's current t1
-                    if (is_rect)
-                        ok = rect_hit(kind, sc.prim_a[p], sc.prim_b[p], sc.prim_c[p], sc.prim_d[p], sc.prim_e[p], ro, rd, t0, closest, t);
-                    else
-                        ok = sphere_hit(Vec<F>(sc.prim_a[p], sc.prim_b[p], sc.prim_c[p]), F(sc.prim_d[p]), ro, rd, t0, t1, t) &&
-                             !(t > closest);
-                    if (!ok) continue;
-                    bool take = !any || t < closest;
-                    if (!take) {  // tie with the current winner
-                        const uint32_t cur = (uint32_t)rec.prim;
-                        if (is_rect && best_is_rect) take = p > cur;
-                        else if (is_rect != best_is_rect) take = is_rect;
-                        else take = p < cur;
-                    }
-                    if (!take) continue;
-                    closest = t;
-                    any = true;
-                    best_is_rect = is_rect;
-                    Hit<F> local;
-                    local.t = t;
-                    local.p = ro + rd * t;
-                    if (!is_rect)
-                        local.n = (local.p - Vec<F>(sc.prim_a[p], sc.prim_b[p], sc.prim_c[p])) / F(sc.prim_d[p]);
-                    else
-                        local.n = Vec<F>(kind == RTX_PRIM_RECT_YZ ? 1.0f : 0.0f, kind == RTX_PRIM_RECT_XZ ? 1.0f : 0.0f,
-                                         kind == RTX_PRIM_RECT_XY ? 1.0f : 0.0f);
-                    fill_uv(p, kind, ro, rd, t, local);
-                    if (sc.prim_flip[p]) local.n = -local.n;
-                    local.prim = (int)p;
-                    local.material = sc.prim_material[p];
-                    for (uint32_t s = se; s > sb; --s) {  // Rotate.cpp:12-13, Translate.cpp:9
-                        const uint32_t q = s - 1;
-                        if (sc.step_kind[q] == RTX_STEP_TRANSLATE) {
-                            local.p = local.p + Vec<F>(sc.step_x[q], sc.step_y[q], sc.step_z[q]);
-                        } else {
-                            F qx = sc.step_x[q], qy = sc.step_y[q], qz = sc.step_z[q], qw = sc.step_w[q];
-                            local.p = rotate(qx, qy, qz, qw, local.p);
-                            local.n = rotate(qx, qy, qz, qw, local.n);
-                        }
-                    }
-                    rec = local;
-                }
+            }
+            rec = local;
+        }
+    }
+
+    // The nearest hit through a tree handed in from outside, walked as the GPU kernel walks its
+    // two-child nodes (trace_bvh_kernel in raytrace_amd/csrc/rtx_core.h): the items outside the tree
+    // first; then from the root, whose own box is not tested: at an inner node both children's boxes
+    // against the ray (12 counted operations per box: one subtraction and one multiplication per
+    // plane), the nearer child next and the farther one deferred when both are met; a leaf tests its
+    // item.  A deferred child is not tested again when it is taken up.
+    bool world_hit_tree(const Vec<F>& o, const Vec<F>& d, F t0, F t1, Hit<F>& rec) {
+        const Vec<F> inv(F(1.0f) / d.x, F(1.0f) / d.y, F(1.0f) / d.z);
+        F closest = t1;
+        bool any = false, best_is_rect = false;
+        const int n_items = (int)m_bvh->items.size();
+        for (int k = n_items - m_bvh->n_big; k < n_items; ++k) test_item(m_bvh->items[k], o, d, t0, t1, closest, any, best_is_rect, rec);
+        if (m_bvh->nodes.empty()) return any;
+        auto slab = [&](const BvhNodeCpu& N, float& t_near) {
+            float tn = raw(t0), tf = raw(closest);
+            for (int a = 0; a < 3; ++a) {
+                const float ta = raw((F(N.lo[a]) - o.at(a)) * inv.at(a)), tb = raw((F(N.hi[a]) - o.at(a)) * inv.at(a));
+                if (ta != ta || tb != tb) continue;  // 0 * inf: the ray lies in a bounding plane
+                tn = std::max(tn, std::min(ta, tb));
+                tf = std::min(tf, std::max(ta, tb));
+            }
+            t_near = tn;
+            return tn <= tf;
+        };
+        int stack[64], sp = 0, cur = 0;
+        for (;;) {
+            const BvhNodeCpu& N = m_bvh->nodes[cur];
+            if (N.left < 0) {  // leaf
+                for (int k = N.first; k < N.first + N.count; ++k) test_item(m_bvh->items[k], o, d, t0, t1, closest, any, best_is_rect, rec);
+                if (sp == 0) break;
+                cur = stack[--sp];
+                continue;
+            }
+            ++tree_nodes;
+            float n0, n1;
+            const bool h0 = slab(m_bvh->nodes[N.left], n0), h1 = slab(m_bvh->nodes[N.right], n1);
+            if (h0 && h1) {
+                const bool first0 = n0 <= n1;
+                if (sp >= 64) return any;  // (the builder bounds the depth far below this)
+                stack[sp++] = first0 ? N.right : N.left;
+                cur = first0 ? N.left : N.right;
+            } else if (h0 || h1) {
+                cur = h0 ? N.left : N.right;
+            } else {
+                if (sp == 0) break;
+                cur = stack[--sp];
             }
         }
         return any;
@@ -817,6 +882,9 @@ private:
 };
 
 std::atomic<int> g_use_bvh(0);
+Bvh g_external_tree;                                 // restate_set_external_tree
+std::atomic<int> g_has_external_tree(0);
+std::atomic<unsigned long long> g_last_tree_nodes(0);  // inner nodes visited by the last render through it
 
 template <class F>
 int render_impl(const RtxScene* scene, int nx, int ny, int spp_begin, int spp_count, uint64_t seed, int max_depth,
@@ -826,10 +894,12 @@ int render_impl(const RtxScene* scene, int nx, int ny, int spp_begin, int spp_co
     std::atomic<int> next_row(0);
     std::atomic<unsigned long long> rays(0), flops(0);
     Bvh bvh;
-    const bool use_bvh = g_use_bvh.load() != 0;
-    if (use_bvh) bvh = build_bvh(*scene);
+    const bool external = g_has_external_tree.load() != 0;
+    const bool use_bvh = g_use_bvh.load() != 0 || external;
+    if (use_bvh && !external) bvh = build_bvh(*scene);
+    std::atomic<unsigned long long> tree_nodes(0);
     auto worker = [&]() {
-        Tracer<F> tr(*scene, max_depth, use_bvh ? &bvh : nullptr);
+        Tracer<F> tr(*scene, max_depth, external ? &g_external_tree : (use_bvh ? &bvh : nullptr));
         g_flops = 0;
         for (;;) {
             int j = next_row.fetch_add(1);
@@ -860,6 +930,7 @@ int render_impl(const RtxScene* scene, int nx, int ny, int spp_begin, int spp_co
         }
         rays += tr.segments;
         flops += g_flops;
+        tree_nodes += tr.tree_nodes;
     };
     if (n_threads <= 1) {
         worker();
@@ -870,6 +941,7 @@ int render_impl(const RtxScene* scene, int nx, int ny, int spp_begin, int spp_co
     }
     if (total_rays) *total_rays = rays.load();
     if (total_flops) *total_flops = flops.load();
+    g_last_tree_nodes.store(tree_nodes.load());
     return 0;
 }
 
@@ -894,6 +966,39 @@ int restate_count_flops(const RtxScene* scene, int nx, int ny, int spp_begin, in
 
 /* 1: later calls walk this file's own bounding-volume hierarchy instead of scanning the list. */
 void restate_set_bvh(int on) { g_use_bvh.store(on); }
+
+/* Later renders walk this tree instead (n_nodes = 0: back to the list / this file's own hierarchy):
+ * one record per box, record 0 the root, left / right < 0 for a leaf whose items are
+ * [first, first + count); the last n_big items lie outside the tree.  The arrays are copied. */
+void restate_set_external_tree(int n_items, const uint32_t* item_begin, const uint32_t* item_end, int n_big, int n_nodes,
+                               const float* lo, const float* hi, const int32_t* left, const int32_t* right,
+                               const int32_t* first, const int32_t* count) {
+    g_has_external_tree.store(0);
+    g_external_tree = Bvh{};
+    if (n_nodes <= 0) return;
+    g_external_tree.two_child_order = true;
+    g_external_tree.n_big = n_big;
+    g_external_tree.items.resize((size_t)n_items);
+    for (int k = 0; k < n_items; ++k) {
+        g_external_tree.items[k].prim_begin = item_begin[k];
+        g_external_tree.items[k].prim_end = item_end[k];
+    }
+    g_external_tree.nodes.resize((size_t)n_nodes);
+    for (int k = 0; k < n_nodes; ++k) {
+        BvhNodeCpu& N = g_external_tree.nodes[k];
+        for (int a = 0; a < 3; ++a) {
+            N.lo[a] = lo[3 * k + a];
+            N.hi[a] = hi[3 * k + a];
+        }
+        N.left = left[k];
+        N.right = right[k];
+        N.first = first[k];
+        N.count = count[k];
+    }
+    g_has_external_tree.store(1);
+}
+/* Inner nodes visited by the last render through an external tree. */
+unsigned long long restate_last_tree_nodes(void) { return g_last_tree_nodes.load(); }
 
 /* Nearest hit of n rays (Shape::hit of the world). */
 int restate_hit(const RtxScene* scene, uint32_t n, const float* org, const float* dir, float t0, float t1, RtxHit* hits) {

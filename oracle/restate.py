@@ -58,8 +58,8 @@ class _accel:
         load().restate_set_bvh(0)
 
 
-def render(scene, w, h, spp_begin, spp_count, seed=0, threads=1, per_sample=False, max_depth=50, bvh=False):
-    with _accel(bvh):
+def render(scene, w, h, spp_begin, spp_count, seed=0, threads=1, per_sample=False, max_depth=50, bvh=False, tree=None):
+    with _accel(bvh), _external_tree(tree):
         return _render(scene, w, h, spp_begin, spp_count, seed, threads, per_sample, max_depth)
 
 
@@ -80,14 +80,46 @@ def _render(scene, w, h, spp_begin, spp_count, seed, threads, per_sample, max_de
     return out
 
 
-def count_flops(scene, w, h, spp_begin, spp_count, seed=0, threads=1, max_depth=50, bvh=False):
+class _external_tree:
+    """Scope in which the nearest-hit query walks a tree handed in from outside (a dict of arrays as
+    tests/tree_export.cpp hands them out: item_begin, item_end, n_big, lo, hi, left, right, first,
+    count) the way the GPU kernel walks its two-child nodes.  None: no change."""
+
+    def __init__(self, tree):
+        self.tree = tree
+
+    def __enter__(self):
+        if self.tree is None:
+            return
+        lib = load()
+        lib.restate_set_external_tree.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6
+        lib.restate_set_external_tree.restype = None
+        lib.restate_last_tree_nodes.restype = C.c_ulonglong
+        t = self.tree
+        a = {k: np.ascontiguousarray(t[k]) for k in ("item_begin", "item_end", "lo", "hi", "left", "right", "first", "count")}
+        lib.restate_set_external_tree(len(a["item_begin"]), a["item_begin"].ctypes.data, a["item_end"].ctypes.data,
+                                      int(t["n_big"]), len(a["left"]), a["lo"].ctypes.data, a["hi"].ctypes.data,
+                                      a["left"].ctypes.data, a["right"].ctypes.data, a["first"].ctypes.data,
+                                      a["count"].ctypes.data)
+
+    def __exit__(self, *exc):
+        if self.tree is not None:
+            load().restate_set_external_tree(0, None, None, 0, 0, None, None, None, None, None, None)
+
+
+def count_flops(scene, w, h, spp_begin, spp_count, seed=0, threads=1, max_depth=50, bvh=False, tree=None):
+    """Counted fp32 operations and rays of a render; with `tree` (see _external_tree) also the inner
+    nodes the queries visited, as "tree_nodes"."""
     lib = load()
     rays, flops = C.c_uint64(0), C.c_uint64(0)
-    with _accel(bvh):
+    with _accel(bvh), _external_tree(tree):
         rc = lib.restate_count_flops(_scene_ptr(scene), w, h, spp_begin, spp_count, seed, max_depth, threads,
                                      C.byref(rays), C.byref(flops))
-    assert rc == 0
-    return {"rays": rays.value, "flops": flops.value}
+        assert rc == 0
+        out = {"rays": rays.value, "flops": flops.value}
+        if tree is not None:
+            out["tree_nodes"] = int(lib.restate_last_tree_nodes())
+    return out
 
 
 def hit(scene, origins, directions, t0=0.001, t1=3.402823466e+38, bvh=False):

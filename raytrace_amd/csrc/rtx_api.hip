@@ -555,35 +555,13 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
 
     const bool use_bvh = accel == RTX_ACCEL_BVH || (accel == RTX_ACCEL_AUTO && s->n_prims > 64);
 
-    std::vector<rtxd::Prim> prims(s->n_prims);
-    for (uint32_t p = 0; p < s->n_prims; ++p) {
-        rtxd::Prim& P = prims[p];
-        P.a = s->prim_a[p]; P.b = s->prim_b[p]; P.c = s->prim_c[p]; P.d = s->prim_d[p]; P.e = s->prim_e[p];
-        P.kind_flip = s->prim_kind[p] | (s->prim_flip[p] ? 4u : 0u);
-        P.material = s->prim_material[p];
-        P.group = 0;
-    }
-    std::vector<rtxd::Step> steps(s->n_steps);
-    for (uint32_t k = 0; k < s->n_steps; ++k) {
-        rtxd::Step& S = steps[k];
-        S.x = s->step_x[k]; S.y = s->step_y[k]; S.z = s->step_z[k]; S.w = s->step_w[k];
-        S.kind = s->step_kind[k];
-        S.pad[0] = S.pad[1] = S.pad[2] = 0;
-    }
-    // Groups: runs of consecutive primitives under one chain.  For the linear scan a
-    // run of untransformed primitives is one group; for the BVH every untransformed
-    // primitive is its own item so the tree can separate them.
+    // primitives, transform steps and the groups the scan walks / the tree is built over
+    std::vector<rtxd::Prim> prims;
+    std::vector<rtxd::Step> steps;
     std::vector<rtxd::Group> groups;
-    for (uint32_t p = 0; p < s->n_prims;) {
-        uint32_t c = s->prim_chain[p];
-        uint32_t q = p + 1;
-        if (!(use_bvh && c == 0))
-            while (q < s->n_prims && s->prim_chain[q] == c) ++q;
-        for (uint32_t k = p; k < q; ++k) prims[k].group = (uint32_t)groups.size();
-        if (use_bvh && q - p >= (1u << 24))  // a leaf record counts the primitives of a group in 24 bits
-            return fail(RTX_ERR_TOO_LARGE, "more than 2^24 primitives under one transform chain");
-        groups.push_back(rtxd::Group{p, q, s->chain_begin[c], s->chain_begin[c + 1]});
-        p = q;
+    {
+        std::string err;
+        if (!rtxbvh::scene_groups(s, use_bvh, prims, steps, groups, err)) return fail(RTX_ERR_TOO_LARGE, err);
     }
     std::vector<rtxd::Material> mats(s->n_materials);
     for (uint32_t m = 0; m < s->n_materials; ++m)

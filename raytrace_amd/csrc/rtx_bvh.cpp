@@ -141,6 +141,40 @@ void store_box(uint16_t q[3][2], const Box& b, const Grid& g) {
 
 }  // namespace
 
+bool scene_groups(const RtxScene* s, bool for_tree, std::vector<rtxd::Prim>& prims, std::vector<rtxd::Step>& steps,
+                  std::vector<rtxd::Group>& groups, std::string& err) {
+    prims.assign(s->n_prims, rtxd::Prim{});
+    for (uint32_t p = 0; p < s->n_prims; ++p) {
+        rtxd::Prim& P = prims[p];
+        P.a = s->prim_a[p]; P.b = s->prim_b[p]; P.c = s->prim_c[p]; P.d = s->prim_d[p]; P.e = s->prim_e[p];
+        P.kind_flip = s->prim_kind[p] | (s->prim_flip[p] ? 4u : 0u);
+        P.material = s->prim_material[p];
+        P.group = 0;
+    }
+    steps.assign(s->n_steps, rtxd::Step{});
+    for (uint32_t k = 0; k < s->n_steps; ++k) {
+        rtxd::Step& S = steps[k];
+        S.x = s->step_x[k]; S.y = s->step_y[k]; S.z = s->step_z[k]; S.w = s->step_w[k];
+        S.kind = s->step_kind[k];
+        S.pad[0] = S.pad[1] = S.pad[2] = 0;
+    }
+    groups.clear();
+    for (uint32_t p = 0; p < s->n_prims;) {
+        const uint32_t c = s->prim_chain[p];
+        uint32_t q = p + 1;
+        if (!(for_tree && c == 0))
+            while (q < s->n_prims && s->prim_chain[q] == c) ++q;
+        for (uint32_t k = p; k < q; ++k) prims[k].group = (uint32_t)groups.size();
+        if (for_tree && q - p >= (1u << 24)) {  // a leaf record counts the primitives of a group in 24 bits
+            err = "more than 2^24 primitives under one transform chain";
+            return false;
+        }
+        groups.push_back(rtxd::Group{p, q, s->chain_begin[c], s->chain_begin[c + 1]});
+        p = q;
+    }
+    return true;
+}
+
 bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,
            const std::vector<rtxd::Step>& steps, Tree& out, std::string& err) {
     std::vector<TmpNode> nodes;

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "rtx.h"
 #include "rtx_device.h"
 
 namespace rtxbvh {
@@ -37,6 +38,15 @@ struct Tree {
     float origin[3] = {0, 0, 0};
     float scale[3] = {1, 1, 1};
 };
+
+// The caller's flattened scene as device records: primitives, transform steps, and the groups -
+// runs of consecutive primitives under one transform chain - that the linear scan walks and the
+// tree is built over.  For the scan (`for_tree` false) a run of untransformed primitives is one
+// group; for the tree every untransformed primitive is an item of its own, so that the tree can
+// separate them, and a transformed run (a Box under Rotate / Translate) stays one item.  Returns
+// false (and sets err) when a transformed run is too long for a leaf record's count.
+bool scene_groups(const RtxScene* s, bool for_tree, std::vector<rtxd::Prim>& prims, std::vector<rtxd::Step>& steps,
+                  std::vector<rtxd::Group>& groups, std::string& err);
 
 // Returns false (and sets err) if the tree cannot be built within kMaxDepth.
 bool build(const std::vector<rtxd::Prim>& prims, const std::vector<rtxd::Group>& groups,

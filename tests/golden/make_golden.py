@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import ref, restate  # noqa: E402
 from raytrace_amd import api  # noqa: E402
+from tests import util  # noqa: E402
 
 SAMPLE_CASES = [  # scene, w, h, spp_begin, spp, seed
     ("cornell", 64, 36, 0, 16, 7),
@@ -275,6 +276,22 @@ def flops_per_ray():
         flops[name + ":bvh"] = dict(flops_per_ray=c["flops"] / c["rays"], rays=c["rays"], flops=c["flops"], w=w, h=h, spp=spp,
                                     note="the restatement's own BVH traversal (median split, leaves of <= 2 items)")
         print("flops/ray", name + ":bvh", flops[name + ":bvh"]["flops_per_ray"])
+    # ... and the same rays through the tree the GPU kernel walks: the renderer's own builder
+    # (binned surface-area splits, one item per leaf, big items outside the tree), exported by
+    # tests/tree_export.cpp, walked in the kernel's order (both children tested on arrival: 2 x 12
+    # counted operations per inner node visited; nearer child first)
+    for name, w, h, spp in (("random_field", 240, 135, 2), ("bvh_stress", 240, 135, 1)):
+        hs = api.HostScene(name, w, h)
+        tree = util.product_tree(hs)
+        c = restate.count_flops(hs, w, h, 0, spp, seed=0, threads=8, tree=tree)
+        flops[name + ":bvh_product"] = dict(
+            flops_per_ray=c["flops"] / c["rays"], rays=c["rays"], flops=c["flops"], w=w, h=h, spp=spp,
+            inner_nodes_per_ray=c["tree_nodes"] / c["rays"], tree_depth=int(tree["depth"]), tree_items=len(tree["item_begin"]),
+            tree_visits_estimate=float(tree["visits"]),
+            note="the renderer's own tree (rtx_bvh.cpp) walked in the kernel's order: 24 per inner node visited "
+                 "+ the item tests it reaches + shading")
+        print("flops/ray", name + ":bvh_product", flops[name + ":bvh_product"]["flops_per_ray"],
+              "inner nodes / ray", flops[name + ":bvh_product"]["inner_nodes_per_ray"])
     with open(os.path.join(HERE, "flops_per_ray.json"), "w") as f:
         json.dump(flops, f, indent=1, sort_keys=True)
 

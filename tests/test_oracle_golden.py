@@ -264,3 +264,36 @@ def test_jpeg_fixtures_are_what_the_references_loader_returns(tmp_path):
         path.write_bytes(g[name + "_file"].tobytes())
         got = ref.load_image(path)
         assert got is not None and np.array_equal(got, g[name + "_texels"]), name
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("bvh_stress_500", 32, 18, 3), ("random_field", 32, 18, 2), ("cornell_extra", 32, 18, 4)])
+def test_the_renderers_tree_walked_on_the_host_finds_the_scans_hits(name, w, h, spp):
+    """The tree of the renderer's own builder (raytrace_amd/csrc/rtx_bvh.cpp, exported by
+    tests/tree_export.cpp with its 16-bit boxes decoded) walked by the CPU restatement in the GPU
+    kernel's order: the tree only prunes ShapeList::hit's scan (ShapeList.cpp:5-17), so every sample
+    must come out bit for bit as from the scan.  This is the walk whose operations price a ray of the
+    BVH workloads (tests/golden/flops_per_ray.json, keys ":bvh_product")."""
+    scene = api.HostScene(name, w, h)
+    tree = util.product_tree(scene)
+    assert len(tree["item_begin"]) >= 5 and tree["depth"] >= 2
+    a = restate.render(scene, w, h, 0, spp, seed=5, threads=4, per_sample=True)
+    b = restate.render(scene, w, h, 0, spp, seed=5, threads=4, per_sample=True, tree=tree)
+    assert np.array_equal(a["segments"], b["segments"])
+    assert np.array_equal(a["samples"], b["samples"], equal_nan=True)
+
+
+def test_flops_fixture_prices_tree_scenes_with_the_renderers_tree():
+    import json
+    import os
+
+    table = json.load(open(os.path.join(util.GOLDEN, "flops_per_ray.json")))
+    for scene in ("random_field", "bvh_stress"):
+        own, product = table[scene + ":bvh"], table[scene + ":bvh_product"]
+        assert product["rays"] == own["rays"]  # the same rays
+        assert 100 < product["flops_per_ray"] < own["flops_per_ray"]  # near-first order over surface-area splits visits less
+        assert product["inner_nodes_per_ray"] * 24 < product["flops_per_ray"]
+    # a small case live: the counted operations are those of the fixture's method
+    scene = api.HostScene("random_field", 48, 27)
+    c = restate.count_flops(scene, 48, 27, 0, 1, seed=0, threads=4, tree=util.product_tree(scene))
+    assert abs(c["flops"] / c["rays"] / table["random_field:bvh_product"]["flops_per_ray"] - 1) < 0.1
+    assert abs(c["tree_nodes"] / c["rays"] / table["random_field:bvh_product"]["inner_nodes_per_ray"] - 1) < 0.1
