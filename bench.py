@@ -54,6 +54,12 @@ WORKLOADS = {
 }
 
 
+# Samples per pixel of one frame (or progressive step) of each configuration as a whole, which N GPUs split
+# N ways (--share-of N): the 4096-spp Cornell frame, the 1024-spp BVH frames, the 256-spp steps of the 4K frame.
+FRAME_SPP = {"cornell_1080p": 4096, "random_field_1080p": 1024, "bvh_stress_1080p": 1024, "cornell_extra_4k": 256,
+             "small_400x225": 100}
+
+
 def load_flops_per_ray(scene: str, bvh: bool):
     """Algorithmic fp32 operations per ray, counted by the op-counting build of the CPU
     restatement (tests/golden/flops_per_ray.json, made by tests/golden/make_golden.py): the
@@ -169,17 +175,22 @@ def cpu_baseline(scene: str, w: int, h: int, threads: int, seconds_budget: float
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cornell_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--spp-per-step", type=int, default=0)
+    ap.add_argument("--share-of", type=int, default=0,
+                    help="render this GPU's share of the configuration split over that many GPUs: samples per step = the "
+                         "configuration's frame (or progressive step) / SHARE_OF, e.g. 8 -> 512 / 128 / 128 / 32 spp for the "
+                         "Cornell, sphere-field, 100 000-item and 4K workloads")
     ap.add_argument("--width", type=int, default=0, help="override the workload's frame width (tests)")
     ap.add_argument("--height", type=int, default=0, help="override the workload's frame height (tests)")
     ap.add_argument("--mode", default="fast", choices=["fast", "deterministic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true",
-                    help="reduce / resolve on the render stream and a synchronous copy back of the image after every "
-                         "step: per-kernel counters then see the trace kernel alone")
+                    help="one render stream (the launches of consecutive steps do not overlap), reduce / resolve on it "
+                         "and a synchronous copy back of the image after every step: per-kernel counters and "
+                         "durations then see the trace kernel alone")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--single-process", action="store_true",
                     help="one process drives all --gpus devices through rtx_render_multi (the C ABI's own split: "
@@ -407,7 +418,7 @@ def main() -> int:
 
     scene_name, w, h, spp_default = WORKLOADS[args.workload]
     w, h = args.width or w, args.height or h
-    spp = args.spp_per_step or spp_default
+    spp = args.spp_per_step or (max(1, FRAME_SPP[args.workload] // args.share_of) if args.share_of else spp_default)
     mode = api.RTX_MODE_FAST if args.mode == "fast" else api.RTX_MODE_DETERMINISTIC
 
     engine = None
@@ -444,7 +455,12 @@ def main() -> int:
         if engine is None:
             torch.cuda.synchronize(dev)
 
-    step_accum = [torch.zeros((h, w, 3), dtype=torch.float32, device=dev) for _ in range(2)]  # this GPU's steps
+    # Consecutive steps are launched on two streams in turn (unless --serial): a launch ends on its slowest
+    # waves, and the next step - an independent sample range into another accumulator - fills the CUs they
+    # leave idle (measured, kernels alone: Cornell box 1080p x 512 spp 103.4 -> 110.4 Grays/s, the 4K frame
+    # x 32 spp 72.9 -> 79.4, the 100 000-item scene x 128 spp 8.14 -> 8.46).  Three accumulators rotate.
+    overlap = engine is None and not args.serial
+    step_accum = [torch.zeros((h, w, 3), dtype=torch.float32, device=dev) for _ in range(3 if overlap else 2)]  # this GPU's steps
     frame_accum = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)  # rank 0: running frame
     rays = torch.zeros(1, dtype=torch.int64, device=dev)
     if engine is None:
@@ -456,13 +472,13 @@ def main() -> int:
         copy_stream = torch.cuda.Stream(dev) if rank == 0 else None  # the copy back of a step's image
         copied = [None]
         render_stream = torch.cuda.current_stream(dev)
-        # reduce + resolve of step k while step k+1 renders.  With one GPU there is no reduce to hide: the
-        # frame addition and the resolve take 25 us behind the trace kernel on its own stream, but 1 ms
-        # each - and 1 % of the next step's rendering - when they share the GPU with it from a second stream
-        # (measured: 103.3 against 102.2 Grays/s whole job), so a single rank runs them in line.
-        side_stream = render_stream if (args.serial or world == 1) else torch.cuda.Stream(dev)
+        render_streams = [render_stream, torch.cuda.Stream(dev)] if overlap else [render_stream]
+        # reduce (N > 1), frame addition and resolve of a step on a stream of their own, in step order, while
+        # the next steps render; --serial: in line behind the step's trace kernel
+        side_stream = render_stream if args.serial else torch.cuda.Stream(dev)
     else:
         render_stream = side_stream = None
+        render_streams = None
     ev = {}
 
     total_spp_done = 0
@@ -479,12 +495,13 @@ def main() -> int:
                 ev[k] = (time.perf_counter() - t) * 1e3
             return
         p = ctx.params(w, h, begin, spp, mode=mode, seed=0, accumulate=False)
+        stream = torch.cuda.current_stream(dev)  # the render stream this step was given
         if timed:
             ev[k] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[k][0].record(render_stream)  # on the stream the kernel is launched on
-        ctx.render_device(p, buf.data_ptr(), rays.data_ptr(), render_stream.cuda_stream)
+            ev[k][0].record(stream)  # on the stream the kernel is launched on
+        ctx.render_device(p, buf.data_ptr(), rays.data_ptr(), stream.cuda_stream)
         if timed:
-            ev[k][1].record(render_stream)
+            ev[k][1].record(stream)
 
     def combine(k: int, buf):
         nonlocal total_spp_done
@@ -517,7 +534,7 @@ def main() -> int:
         return None
 
     trace("scene uploaded, warm-up")
-    run_pipelined_steps(range(args.warmup), render, combine, step_accum, render_stream, side_stream)
+    run_pipelined_steps(range(args.warmup), render, combine, step_accum, render_streams, side_stream)
     sync()
     trace("warm-up done")
     rays.zero_()
@@ -529,7 +546,7 @@ def main() -> int:
     sync()
     t0 = time.perf_counter()
     images = run_pipelined_steps(range(args.warmup, args.warmup + args.steps), render, combine, step_accum,
-                                 render_stream, side_stream)
+                                 render_streams, side_stream)
     sync()
     trace("timed steps done")
     if world > 1:
@@ -546,13 +563,22 @@ def main() -> int:
     n_rays = int(rays_total.item())
     my_rays = int(rays.item())
     kernel_ms = [v if engine is not None else v[0].elapsed_time(v[1]) for v in ev.values()]
+    # The time the trace kernels of the timed steps had the GPU, per launch: from the start of the first to
+    # the end of the last (HIP events on the kernels' own streams).  With one render stream that is their
+    # average duration plus the gaps between them; with two, consecutive launches overlap and each one's
+    # own duration also covers the time it shared the GPU with its neighbours.
+    if engine is None and ev:
+        first = min(ev)
+        kernel_span_ms = max(ev[first][0].elapsed_time(v[1]) for v in ev.values()) / len(ev)
+    else:
+        kernel_span_ms = float(np.mean(kernel_ms))
 
     if rank == 0:
         if args.dump_frame:
             np.save(args.dump_frame, frame_accum.cpu().numpy())
         samples = w * h * spp * world * args.steps
         flops_per_ray, flops_src, flops_ref_tree = load_flops_per_ray(scene_name, bvh)
-        avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
+        avg_kernel_s = kernel_span_ms * 1e-3
         rays_per_launch = my_rays / args.steps
         achieved_tflops = None if flops_per_ray is None else flops_per_ray * rays_per_launch / avg_kernel_s / 1e12
         out = {
@@ -575,12 +601,14 @@ def main() -> int:
                 "width": w, "height": h,
                 "spp_per_step_per_gpu": spp,
                 "spp_total": spp * world * args.steps,
+                "share_of": args.share_of or None,
                 "max_depth": 50,
                 "mode": args.mode,
                 "accel": "bvh" if bvh else "linear",
                 "parallelism": (f"spp-split x{world}, reduce(sum) of fp32 accumulators to rank 0 per step, "
-                                "overlapped with the next step's rendering") if world > 1 else
-                               "one GPU: frame addition and resolve of a step in line behind its trace kernel",
+                                "overlapped with the next steps' rendering") if world > 1 else
+                               ("one GPU: frame addition and resolve of a step in line behind its trace kernel" if args.serial or engine
+                                is not None else "one GPU: consecutive steps on two streams, frame addition and resolve on a third"),
             },
             "spp_per_s": spp * world * args.steps / elapsed,
             "msamples_per_s": samples / elapsed / 1e6,
@@ -594,8 +622,14 @@ def main() -> int:
                 "traffic": load_hbm_traffic(args.workload, spp),
                 "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/hbm_traffic.json)",
                 "kernel": trace_kernel_name(args.mode, bvh) if engine is None else args.engine,
-                "kernel_ms_avg": float(np.mean(kernel_ms)),
-                "kernel_ms_min": float(np.min(kernel_ms)),
+                "kernel_ms_avg": kernel_span_ms,
+                "kernel_ms_avg_note": "start of the first to end of the last timed launch / launches (HIP events on the "
+                                      "kernels' streams)" + ("; consecutive launches overlap on two streams, a launch's own "
+                                                             "duration (kernel_ms_each_avg) includes the time it shares the GPU"
+                                                             if overlap else ""),
+                "kernel_ms_each_avg": float(np.mean(kernel_ms)),
+                "kernel_ms_each_min": float(np.min(kernel_ms)),
+                "launch_streams": len(render_streams) if render_streams else 1,
                 "rays_per_launch": rays_per_launch,
                 "kernel_grays_per_s": rays_per_launch / avg_kernel_s / 1e9,
                 "flops_per_ray": flops_per_ray,

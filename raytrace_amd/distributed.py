@@ -52,45 +52,55 @@ def render_frame(render_range: Callable[[int, int], "object"], total_spp: int, r
 def run_pipelined_steps(steps: Sequence[int], render: Callable[[int, "object"], None],
                         combine: Callable[[int, "object"], "object"], buffers: Sequence["object"],
                         render_stream=None, side_stream=None) -> list:
-    """Progressive steps with the exchange of step k hidden behind the rendering of step k+1.
+    """Progressive steps with the exchange of step k hidden behind the rendering of the steps after it.
 
-    `render(step, buf)` enqueues the rendering of `step` into the accumulator `buf`;
-    `combine(step, buf)` sum-reduces `buf` to rank 0 and consumes it there (adds it to the
-    running frame, resolves); its return values are collected.  Two accumulators alternate, and
-    the rendering of the next step is enqueued BEFORE the current step is combined, so the GPU
-    renders while the previous step's accumulator travels over xGMI and is resolved.  With
-    streams (GPU) `render` runs on `render_stream`, `combine` on `side_stream`, ordered by
-    events in both directions (a buffer is not rendered into again before its last combine has
-    finished); without streams (CPU tensors, gloo) the same order runs synchronously.
+    `render(step, buf)` enqueues the rendering of `step` into the accumulator `buf` (on the current
+    stream); `combine(step, buf)` sum-reduces `buf` to rank 0 and consumes it there (adds it to the
+    running frame, resolves); its return values are collected.  The accumulators are used in turn,
+    and the rendering of the next len(buffers) - 1 steps is enqueued BEFORE the current step is
+    combined, so the GPU renders while an earlier step's accumulator travels over xGMI and is
+    resolved.  With streams (GPU) `render` runs on `render_stream`, `combine` on `side_stream`,
+    ordered by events in both directions (a buffer is not rendered into again before its last
+    combine has finished); without streams (CPU tensors, gloo) the same order runs synchronously.
+
+    `render_stream` may be a list of streams: consecutive steps then go to them in turn, so that the
+    trace kernel of one step starts while the last waves of the step before it finish (a launch ends
+    on its slowest waves; steps are independent, so the next one can fill the CUs they leave idle).
+    That needs one more accumulator than streams.
     """
-    if len(buffers) != 2:
-        raise ValueError("two accumulators alternate")
     steps = list(steps)
     cuda = render_stream is not None
+    streams = list(render_stream) if isinstance(render_stream, (list, tuple)) else [render_stream]
+    n_buf = len(buffers)
+    if n_buf < 2 or (len(streams) > 1 and n_buf < len(streams) + 1):
+        raise ValueError("two accumulators alternate; several render streams need one more accumulator than streams")
     if cuda:
         import torch
-    rendered = [None, None]
-    combined = [None, None]
+    rendered = [None] * n_buf
+    combined = [None] * n_buf
 
     def launch(i: int) -> None:
-        b = i % 2
+        b = i % n_buf
         if cuda:
+            rs = streams[i % len(streams)]
             if combined[b] is not None:
-                render_stream.wait_event(combined[b])
-            with torch.cuda.stream(render_stream):
+                rs.wait_event(combined[b])
+            with torch.cuda.stream(rs):
                 render(steps[i], buffers[b])
-            rendered[b] = render_stream.record_event()
+            rendered[b] = rs.record_event()
         else:
             render(steps[i], buffers[b])
 
     out = []
     if not steps:
         return out
-    launch(0)
+    ahead = n_buf - 1  # steps whose rendering is enqueued before the current one is combined
+    for i in range(min(ahead, len(steps))):
+        launch(i)
     for i, step in enumerate(steps):
-        if i + 1 < len(steps):
-            launch(i + 1)
-        b = i % 2
+        if i + ahead < len(steps):
+            launch(i + ahead)
+        b = i % n_buf
         if cuda:
             side_stream.wait_event(rendered[b])
             with torch.cuda.stream(side_stream):

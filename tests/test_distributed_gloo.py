@@ -57,6 +57,15 @@ def test_pipelined_steps_order_and_buffers():
     assert rd.run_pipelined_steps([], None, None, buffers) == []
     with pytest.raises(ValueError):
         rd.run_pipelined_steps([0], None, None, ["only one"])
+    # a ring of three accumulators: two steps ahead of the combine, each buffer combined before it is reused
+    log.clear()
+    out = rd.run_pipelined_steps(range(5), lambda k, b: log.append(("render", k, b)),
+                                 lambda k, b: log.append(("combine", k, b)) or k, ["A", "B", "C"])
+    assert out == [0, 1, 2, 3, 4]
+    assert log == [("render", 0, "A"), ("render", 1, "B"), ("render", 2, "C"), ("combine", 0, "A"), ("render", 3, "A"),
+                   ("combine", 1, "B"), ("render", 4, "B"), ("combine", 2, "C"), ("combine", 3, "A"), ("combine", 4, "B")]
+    with pytest.raises(ValueError):  # two render streams want three accumulators
+        rd.run_pipelined_steps([0], None, None, ["A", "B"], render_stream=[object(), object()], side_stream=object())
 
 
 def _worker(rank, world, port, out_path):
