@@ -8,6 +8,10 @@ function of the accumulated spp, and preview images at a few steps.
 The ground truth is a separate render (other seed, deterministic mode) of the same scene at
 1/4 resolution per axis and 16x the per-pixel samples of the final frame's 4x4 pixel blocks;
 RMSE is taken on the 4x4 box-filtered frame, so it measures the estimator, not the pixel grid.
+Beside it, where the frame has the fixture's aspect ratio, the RMSE against the REFERENCE tracer's
+own image of the scene (tests/golden/ground_truth_ref_<scene>_240x135.npz: 240 x 135 pixels x 4 096
+spp, rendered by the unmodified reference sources on the CPU): a ground truth that shares nothing
+with the GPU code, at the price of a higher noise floor (the summary states both floors).
 One JSON line per step, then a summary line.
 """
 import argparse
@@ -65,6 +69,16 @@ def main():
     print(json.dumps({"ground_truth": f"{gw}x{gh}, {args.gt_spp} spp, deterministic, seed 4242",
                       "seconds": time.perf_counter() - t0}), flush=True)
 
+    # the reference tracer's own mean image of the scene, if the test fixtures hold one of this aspect ratio
+    ref_gt = None
+    ref_path = os.path.join(ROOT, "tests", "golden", f"ground_truth_ref_{args.scene}_240x135.npz")
+    if os.path.exists(ref_path) and w % 240 == 0 and h % 135 == 0 and w // 240 == h // 135:
+        g = np.load(ref_path)
+        ref_gt = torch.clamp(torch.from_numpy(g["mean"].astype(np.float32)).to(dev), 0.0, 1.0)
+        ref_block = w // 240
+        print(json.dumps({"reference_ground_truth": os.path.relpath(ref_path, ROOT), "spp": int(g["spp"]),
+                          "pixels": "240x135", "block": ref_block}), flush=True)
+
     from raytrace_amd.progressive import ProgressiveFrame
 
     ctx.upload(api.HostScene(args.scene, w, h), api.RTX_ACCEL_AUTO)
@@ -87,12 +101,18 @@ def main():
         small = (frame / spp).reshape(gh, 4, gw, 4, 3).mean(dim=(1, 3))
         mean = torch.clamp(small, 0.0, 1.0)
         rmse = float(torch.sqrt(torch.mean((mean - gt) ** 2)).item())
+        rmse_ref = None
+        if ref_gt is not None:
+            coarse = torch.clamp((frame / spp).reshape(135, ref_block, 240, ref_block, 3).mean(dim=(1, 3)), 0.0, 1.0)
+            rmse_ref = float(torch.sqrt(torch.mean((coarse - ref_gt) ** 2)).item())
         torch.cuda.synchronize(dev)
         ms = a.elapsed_time(b)
         r = int(rays.item()) - rays_before
         if args.checkpoint and ((k + 1) % args.checkpoint_every == 0 or k + 1 == args.steps):
             prog.save(args.checkpoint)
         row = {"step": k + 1, "spp": spp, "kernel_ms": ms, "grays_per_s": r / ms / 1e6, "rmse": rmse}
+        if rmse_ref is not None:
+            row["rmse_vs_reference"] = rmse_ref
         rows.append(row)
         print(json.dumps(row), flush=True)
         if (k + 1) in previews:
@@ -118,7 +138,16 @@ def main():
         shrinking = mid["rmse"] ** 2 - F
         if shrinking > 0 and first["rmse"] ** 2 - F > 0 and mid["spp"] != n1:
             slope_mc = float(0.5 * np.log(shrinking / (first["rmse"] ** 2 - F)) / np.log(mid["spp"] / n1))
-    print(json.dumps({"summary": True, "scene": args.scene, "width": w, "height": h, "steps": args.steps,
+    ref_summary = {}
+    if ref_gt is not None and len(rows) > 2:
+        # the same model against the reference's image: its floor is the reference's own noise at 4 096 spp
+        # (and whatever the two tracers' expectations differ by)
+        r1, r2 = first["rmse_vs_reference"], last["rmse_vs_reference"]
+        A = (r1 ** 2 - r2 ** 2) / (1.0 / first["spp"] - 1.0 / last["spp"])
+        F = r1 ** 2 - A / first["spp"]
+        ref_summary = {"rmse_vs_reference_first": r1, "rmse_vs_reference_last": r2,
+                       "reference_noise_floor_rmse": float(np.sqrt(max(F, 0.0)))}
+    print(json.dumps({"summary": True, "scene": args.scene, "width": w, "height": h, "steps": args.steps, **ref_summary,
                       "spp_per_step": args.spp_per_step, "mean_grays_per_s": float(np.mean([r["grays_per_s"] for r in rows])),
                       "rmse_first": first["rmse"], "rmse_last": last["rmse"], "loglog_slope": float(slope),
                       "ground_truth_noise_floor_rmse": floor, "loglog_slope_above_floor": slope_mc,
