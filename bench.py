@@ -191,6 +191,9 @@ def parse_args(argv=None):
                     help="one render stream (the launches of consecutive steps do not overlap), reduce / resolve on it "
                          "and a synchronous copy back of the image after every step: per-kernel counters and "
                          "durations then see the trace kernel alone")
+    ap.add_argument("--no-specialize", action="store_true",
+                    help="keep the table-driven scan kernel for small scenes (RTX_OPTION_SPECIALIZE_SCAN = 0): A/B against "
+                         "the kernel rtx_upload_scene compiles for the scene")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--single-process", action="store_true",
                     help="one process drives all --gpus devices through rtx_render_multi (the C ABI's own split: "
@@ -448,8 +451,13 @@ def main() -> int:
         trace("process group up")
         ctx = api.Context(local_rank)
         scene = api.HostScene(scene_name, w, h)
+        if args.no_specialize:
+            ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 0)
+        t_upload = time.perf_counter()
         ctx.upload(scene, api.RTX_ACCEL_AUTO)
-        bvh = ctx.info().accel == api.RTX_ACCEL_BVH
+        upload_seconds = time.perf_counter() - t_upload
+        scene_info = ctx.info()
+        bvh = scene_info.accel == api.RTX_ACCEL_BVH
 
     def sync():
         if engine is None:
@@ -605,6 +613,10 @@ def main() -> int:
                 "max_depth": 50,
                 "mode": args.mode,
                 "accel": "bvh" if bvh else "linear",
+                # the scan of a small scene compiled into the kernel at upload (rtx_upload_scene; --no-specialize
+                # keeps the table-driven kernel); the upload's wall time includes that compilation
+                "scan_specialized": bool(scene_info.scan_specialized) if engine is None else None,
+                "upload_seconds": upload_seconds if engine is None else None,
                 "parallelism": (f"spp-split x{world}, reduce(sum) of fp32 accumulators to rank 0 per step, "
                                 "overlapped with the next steps' rendering") if world > 1 else
                                ("one GPU: frame addition and resolve of a step in line behind its trace kernel" if args.serial or engine

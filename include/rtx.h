@@ -197,6 +197,29 @@ const char* rtx_last_error(void);
  * initialised (never fails). */
 int rtx_device_count(void);
 
+/*
+ * Options of a context, set before the calls they affect.  Returns RTX_ERR_INVALID_ARGUMENT for an
+ * unknown option or value.
+ *   RTX_OPTION_SPECIALIZE_SCAN  (default 1) 1: rtx_upload_scene compiles the linear scan of a small
+ *       scene (at most 64 primitives, no tree; a light list and a constant background, the
+ *       reference's own kind of scene, Scene.cpp:83-86,131) into the fast-mode trace kernel with the
+ *       HIP run-time compiler: the scene's records become literals of straight-line code instead of
+ *       a table walked at run time.  Same tests, same arithmetic, same frames; an upload then takes
+ *       about a second longer the first time a process sees the scene.  Where the run-time compiler
+ *       is missing or fails the table-driven kernel renders (rtx_scene_info says which).  0: never.
+ */
+enum { RTX_OPTION_SPECIALIZE_SCAN = 1 };
+int rtx_set_option(RtxContext* ctx, uint32_t option, uint64_t value);
+
+/*
+ * Compile the scene's specialised kernel ahead of its upload, on the calling thread; needs no
+ * context and no GPU (an application can do it on a worker thread while it loads its assets: the
+ * upload of the same scene then finds the code object in the process's cache).  RTX_OK when the
+ * code object is in the cache afterwards; RTX_ERR_UNSUPPORTED when the scene is not one whose scan
+ * is specialised or the run-time compiler is missing or failed (rtx_last_error says which).
+ */
+int rtx_prepare_scene(const RtxScene* scene);
+
 /* Copy the scene to the GPU (and build the BVH when asked or when AUTO decides). */
 int rtx_upload_scene(RtxContext* ctx, const RtxScene* scene, uint32_t accel);
 
@@ -298,8 +321,13 @@ typedef struct RtxSceneInfo {
     uint32_t bvh_depth;    /* inner-node levels above the deepest leaf; 0 without a tree */
     float bvh_visits;      /* the builder's surface-area estimate of the inner nodes a ray through the
                               root box visits (sum of the inner nodes' areas / the root's area) */
+    uint32_t scan_specialized; /* 1: fast-mode frames of this scene run the kernel compiled for it at upload */
+    float specialize_seconds;  /* what that compilation took in this upload (0: reused, or none) */
 } RtxSceneInfo;
 int rtx_scene_info(RtxContext* ctx, RtxSceneInfo* out);
+/* Why the scene's scan was not specialised ("" when it was, or when the scene is not a candidate);
+ * valid until the next upload on the context. */
+const char* rtx_scene_note(RtxContext* ctx);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
 RTX_ABI_VERSION = 5
 RTX_ACCEL_AUTO, RTX_ACCEL_LINEAR, RTX_ACCEL_BVH = 0, 1, 2
+RTX_STEP_TRANSLATE, RTX_STEP_ROTATE = 0, 1
 RTX_MODE_FAST, RTX_MODE_DETERMINISTIC = 0, 1
 RTX_PRIM_RECT_XY, RTX_PRIM_RECT_XZ, RTX_PRIM_RECT_YZ, RTX_PRIM_SPHERE = 0, 1, 2, 3
 RTX_MAT_LAMBERTIAN, RTX_MAT_METAL, RTX_MAT_DIELECTRIC, RTX_MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
@@ -88,7 +89,11 @@ class RtxHit(C.Structure):
 class RtxSceneInfo(C.Structure):
     _fields_ = [("n_prims", C.c_uint32), ("n_items", C.c_uint32),
                 ("n_bvh_nodes", C.c_uint32), ("accel", C.c_uint32),
-                ("bvh_depth", C.c_uint32), ("bvh_visits", C.c_float)]
+                ("bvh_depth", C.c_uint32), ("bvh_visits", C.c_float),
+                ("scan_specialized", C.c_uint32), ("specialize_seconds", C.c_float)]
+
+
+RTX_OPTION_SPECIALIZE_SCAN = 1
 
 
 HIT_DTYPE = np.dtype([("hit", "<i4"), ("prim", "<i4"), ("t", "<f4"),
@@ -99,6 +104,7 @@ RTX_SYMBOLS = (
     "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_device_count", "rtx_upload_scene",
     "rtx_render", "rtx_render_device", "rtx_render_samples", "rtx_hit", "rtx_resolve_device",
     "rtx_scene_info", "rtx_render_multi", "rtx_render_noalloc", "rtx_resolve_to_device",
+    "rtx_set_option", "rtx_prepare_scene", "rtx_scene_note",
 )
 RTX_NOALLOC_MAX_PIXELS = 1 << 21
 RTXH_SYMBOLS = (
@@ -175,8 +181,23 @@ def load_librtx() -> C.CDLL:
         lib.rtx_resolve_to_device.restype = C.c_int
         lib.rtx_scene_info.argtypes = [ctxp, C.POINTER(RtxSceneInfo)]
         lib.rtx_scene_info.restype = C.c_int
+        lib.rtx_set_option.argtypes = [ctxp, C.c_uint32, C.c_uint64]
+        lib.rtx_set_option.restype = C.c_int
+        lib.rtx_prepare_scene.argtypes = [C.POINTER(RtxScene)]
+        lib.rtx_prepare_scene.restype = C.c_int
+        lib.rtx_scene_note.argtypes = [ctxp]
+        lib.rtx_scene_note.restype = C.c_char_p
         _librtx = lib
     return _librtx
+
+
+def prepare_scene(scene) -> None:
+    """rtx_prepare_scene: compile the scene's specialised kernel into the process's cache (no GPU needed)."""
+    lib = load_librtx()
+    ptr = scene.view_ptr if isinstance(scene, HostScene) else C.pointer(scene)
+    rc = lib.rtx_prepare_scene(ptr)
+    if rc != RTX_OK:
+        raise RtxError(rc, lib.rtx_last_error().decode())
 
 
 def load_libhost() -> C.CDLL:
@@ -303,6 +324,13 @@ class Context:
     def upload(self, scene, accel: int = RTX_ACCEL_AUTO):
         ptr = scene.view_ptr if isinstance(scene, HostScene) else C.pointer(scene)
         self._check(self._lib.rtx_upload_scene(self._ctx, ptr, accel))
+
+    def set_option(self, option: int, value: int):
+        self._check(self._lib.rtx_set_option(self._ctx, option, value))
+
+    def note(self) -> str:
+        """Why the uploaded scene's scan was not specialised ("" when it was or is no candidate)."""
+        return self._lib.rtx_scene_note(self._ctx).decode()
 
     def info(self) -> RtxSceneInfo:
         out = RtxSceneInfo()

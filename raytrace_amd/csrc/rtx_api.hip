@@ -17,6 +17,7 @@
 #include "rtx_bvh.h"
 #include "rtx_device.h"
 #include "rtx_launch.h"
+#include "rtx_special.h"
 
 namespace {
 
@@ -119,6 +120,9 @@ struct RtxContext {
     DeviceArray<RtxHit> hits;
     DeviceArray<uint8_t> rgb8;
     DeviceArray<float> peer_frames;  // rtx_render_multi: the other contexts' partial frames, on context 0's GPU
+    bool specialize_scan = true;   // RTX_OPTION_SPECIALIZE_SCAN
+    rtxspecial::Kernel special;    // the trace kernel compiled for the uploaded scene's scan, if any
+    std::string special_note;      // why there is none
     uint64_t scene_hash = 0;  // of everything rtx_upload_scene was given (rtx_render_multi compares it)
     void* scratch = nullptr;  // this device's copy of the file-scope scratch array (rtx_render_noalloc)
 };
@@ -424,6 +428,75 @@ void build_bvh_fast_items(const std::vector<rtxd::Prim>& prims, const std::vecto
     }
 }
 
+// One record per primitive with all the integrator needs after a hit.
+std::vector<rtxd::PrimInfo> prim_infos(const RtxScene* s) {
+    std::vector<rtxd::PrimInfo> info(s->n_prims);
+    for (uint32_t p = 0; p < s->n_prims; ++p) {
+        rtxd::PrimInfo& I = info[p];
+        const uint32_t m = s->prim_material[p];
+        const uint32_t mk = s->mat_kind[m];
+        I.param = s->mat_param[m];
+        I.bits = s->prim_kind[p] | (s->prim_flip[p] ? rtxd::kInfoFlip : 0u) | (mk << rtxd::kInfoMatShift);
+        I.texture = 0;
+        I.r = I.g = I.b = 1.0f;
+        if (mk != RTX_MAT_DIELECTRIC) {
+            const uint32_t t = s->mat_texture[m];
+            I.texture = t;
+            if (s->tex_kind[t] == RTX_TEX_COLOR) {
+                I.r = s->tex_r[t]; I.g = s->tex_g[t]; I.b = s->tex_b[t];
+            } else {
+                I.bits |= rtxd::kInfoTextured;
+                if (texture_needs_uv(s, t, 0)) I.bits |= rtxd::kInfoNeedsUV;
+            }
+        }
+        const uint32_t c = s->prim_chain[p];
+        I.step_begin = s->chain_begin[c];
+        I.step_end = s->chain_begin[c + 1];
+    }
+    return info;
+}
+
+// Whether the scene's light sampling needs the kernels that walk a light tree (nested lists, lights
+// under transforms, enough leaves for a tree over them): what rtx_upload_scene finds while it builds
+// the light tables, from the scene alone.
+bool lights_need_tree(const RtxScene* s) {
+    const uint32_t n_entries = s->n_light_entries ? s->n_light_entries : s->n_lights;
+    const bool general = s->light_sampling == RTX_LIGHTS_GENERAL;
+    size_t with_density = 0;
+    for (uint32_t l = 0; l < n_entries; ++l) {
+        const uint32_t kind = s->light_kind[l];
+        if (kind == RTX_LIGHT_LIST) return true;
+        if (general) {
+            const uint32_t c = s->light_chain ? s->light_chain[l] : 0u;
+            if (s->chain_begin[c + 1] > s->chain_begin[c] || kind == RTX_LIGHT_RECT_XY || kind == RTX_LIGHT_RECT_YZ) return true;
+        }
+        if (kind == RTX_LIGHT_SPHERE || kind == RTX_LIGHT_RECT_XZ || (general && kind <= RTX_LIGHT_RECT_YZ)) ++with_density;
+    }
+    return with_density >= RTX_LIGHT_BVH_MIN;
+}
+
+// A scene whose fast-mode frames run trace_kernel<false, false, false, true>: a scan, a light list
+// without a tree, a constant background.
+bool scan_can_be_specialized(const RtxScene* s, bool use_bvh, bool light_tree) {
+    return !use_bvh && !light_tree && s->light_is_list && s->n_lights != 0 && s->background_mode != RTX_BACKGROUND_SKY;
+}
+
+// A trace kernel compiled for the uploaded scene: the launch rtx_fast_mode::launch_trace makes for a
+// scan scene, through the module API.
+hipError_t launch_special_trace(hipFunction_t kernel, rtxd::TraceArgs a, hipStream_t stream) {
+    rtxd::choose_tile(a.spp_count, a.width, a.height, false, a.tile_w_log2, a.tile_h_log2);
+    const uint32_t bw = 2u << a.tile_w_log2, bh = 2u << a.tile_h_log2;  // 2x2 waves per 256-thread block
+    const uint32_t blocks = ((a.width + bw - 1u) / bw) * ((a.height + bh - 1u) / bh);
+    size_t size = sizeof a;
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(kernel, blocks, 1, 1, 256, 1, 1, 0, stream, nullptr, config);
+}
+hipError_t launch_special_hit(hipFunction_t kernel, rtxd::HitArgs a, hipStream_t stream) {
+    size_t size = sizeof a;
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(kernel, (a.n + 255u) / 256u, 1, 1, 256, 1, 1, 0, stream, nullptr, config);
+}
+
 // FNV-1a over the bytes of the caller's scene: contexts that are to render one frame together
 // must have been given the same arrays.
 struct SceneHasher {
@@ -542,8 +615,40 @@ int rtx_create(int device, RtxContext** out_ctx) {
 void rtx_destroy(RtxContext* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    rtxspecial::unload(ctx->special);
     delete ctx;
 }
+
+int rtx_set_option(RtxContext* ctx, uint32_t option, uint64_t value) {
+    if (!ctx) return fail(RTX_ERR_INVALID_ARGUMENT, "context is null");
+    if (option == RTX_OPTION_SPECIALIZE_SCAN && value <= 1) {
+        ctx->specialize_scan = value != 0;
+        return RTX_OK;
+    }
+    return fail(RTX_ERR_INVALID_ARGUMENT, "unknown option or value");
+}
+
+int rtx_prepare_scene(const RtxScene* s) {
+    int rc = check_scene(s);
+    if (rc != RTX_OK) return rc;
+    if (s->n_prims > 64 || !scan_can_be_specialized(s, false, lights_need_tree(s)))
+        return fail(RTX_ERR_UNSUPPORTED, "not a scene whose scan is specialised (a scan of at most 64 primitives, a light list, a constant background)");
+    std::vector<rtxd::Prim> prims;
+    std::vector<rtxd::Step> steps;
+    std::vector<rtxd::Group> groups;
+    std::string err;
+    if (!rtxbvh::scene_groups(s, false, prims, steps, groups, err)) return fail(RTX_ERR_TOO_LARGE, err);
+    std::vector<rtxd::ScanGroup> scan_groups;
+    std::vector<rtxd::ScanRec> scan_recs;
+    std::vector<rtxd::ScanHit> scan_info;
+    std::vector<uint32_t> scan_orig;
+    build_scan_table(prims, prim_infos(s), groups, steps, scan_groups, scan_recs, scan_info, scan_orig);
+    if (scan_recs.size() - 1 > rtxspecial::kMaxRecords) return fail(RTX_ERR_UNSUPPORTED, "more scan records than a specialised kernel takes");
+    if (!rtxspecial::prepare(rtxspecial::scan_source(scan_groups, scan_recs), err, nullptr)) return fail(RTX_ERR_UNSUPPORTED, err);
+    return RTX_OK;
+}
+
+const char* rtx_scene_note(RtxContext* ctx) { return ctx ? ctx->special_note.c_str() : ""; }
 
 int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     if (!ctx) return fail(RTX_ERR_INVALID_ARGUMENT, "context is null");
@@ -631,30 +736,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
             light_tree = true;  // the kernels that know the tree
         }
     }
-    // one record per primitive with all the integrator needs after a hit
-    std::vector<rtxd::PrimInfo> info(s->n_prims);
-    for (uint32_t p = 0; p < s->n_prims; ++p) {
-        rtxd::PrimInfo& I = info[p];
-        const uint32_t m = s->prim_material[p];
-        const uint32_t mk = s->mat_kind[m];
-        I.param = s->mat_param[m];
-        I.bits = s->prim_kind[p] | (s->prim_flip[p] ? rtxd::kInfoFlip : 0u) | (mk << rtxd::kInfoMatShift);
-        I.texture = 0;
-        I.r = I.g = I.b = 1.0f;
-        if (mk != RTX_MAT_DIELECTRIC) {
-            const uint32_t t = s->mat_texture[m];
-            I.texture = t;
-            if (s->tex_kind[t] == RTX_TEX_COLOR) {
-                I.r = s->tex_r[t]; I.g = s->tex_g[t]; I.b = s->tex_b[t];
-            } else {
-                I.bits |= rtxd::kInfoTextured;
-                if (texture_needs_uv(s, t, 0)) I.bits |= rtxd::kInfoNeedsUV;
-            }
-        }
-        const uint32_t c = s->prim_chain[p];
-        I.step_begin = s->chain_begin[c];
-        I.step_end = s->chain_begin[c + 1];
-    }
+    const std::vector<rtxd::PrimInfo> info = prim_infos(s);
     // the scan requests record p+1 while it tests record p: keep one readable pad record
     std::vector<rtxd::Prim> prims_padded = prims;
     prims_padded.push_back(prims.back());
@@ -756,6 +838,27 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     ctx->info.accel = use_bvh ? RTX_ACCEL_BVH : RTX_ACCEL_LINEAR;
     ctx->info.bvh_depth = use_bvh ? (uint32_t)tree.depth : 0u;
     ctx->info.bvh_visits = use_bvh ? (float)tree.visits : 0.0f;
+    // the scan of a small scene compiled into the fast-mode trace kernel (the variant for a light list and a
+    // constant background: what launch_trace would pick for this scene's frames)
+    rtxspecial::unload(ctx->special);
+    ctx->special_note.clear();
+    ctx->info.scan_specialized = 0;
+    ctx->info.specialize_seconds = 0.0f;
+    if (light_tree != lights_need_tree(s)) return fail(RTX_ERR_HIP, "internal: light tree decision differs");
+    const bool candidate = scan_can_be_specialized(s, use_bvh, light_tree);
+    if (candidate && ctx->specialize_scan) {
+        if (scan_recs.size() - 1 > rtxspecial::kMaxRecords) {
+            ctx->special_note = "more than " + std::to_string(rtxspecial::kMaxRecords) + " scan records";
+        } else {
+            double seconds = 0.0;
+            if (rtxspecial::load(rtxspecial::scan_source(scan_groups, scan_recs), ctx->special, ctx->special_note, &seconds)) {
+                ctx->info.scan_specialized = 1;
+                ctx->info.specialize_seconds = (float)seconds;
+            }
+        }
+    } else if (candidate) {
+        ctx->special_note = "switched off (RTX_OPTION_SPECIALIZE_SCAN)";
+    }
     ctx->scene_hash = hash_scene(s, use_bvh);
     ctx->has_scene = true;
     return RTX_OK;
@@ -778,8 +881,13 @@ int rtx_render_device(RtxContext* ctx, const RtxParams* params, float* d_accum_r
     a.accum = d_accum_rgb;
     a.rays = d_rays;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    if (params->mode == RTX_MODE_DETERMINISTIC) RTX_HIP(rtx_det_mode::launch_trace(a, stream));
-    else RTX_HIP(rtx_fast_mode::launch_trace(a, stream));
+    if (params->mode == RTX_MODE_DETERMINISTIC) {
+        RTX_HIP(rtx_det_mode::launch_trace(a, stream));
+    } else if (ctx->special.frames) {
+        RTX_HIP(launch_special_trace(ctx->special.frames, a, stream));
+    } else {
+        RTX_HIP(rtx_fast_mode::launch_trace(a, stream));
+    }
     return RTX_OK;
 }
 
@@ -950,6 +1058,7 @@ int rtx_render_samples(RtxContext* ctx, const RtxParams* params, float* sample_r
     a.sample_rgb = ctx->sample_rgb.ptr;
     a.sample_segments = ctx->sample_segments.ptr;
     if (params->mode == RTX_MODE_DETERMINISTIC) RTX_HIP(rtx_det_mode::launch_trace(a, nullptr));
+    else if (ctx->special.samples) RTX_HIP(launch_special_trace(ctx->special.samples, a, nullptr));
     else RTX_HIP(rtx_fast_mode::launch_trace(a, nullptr));
     RTX_HIP(hipDeviceSynchronize());
     RTX_HIP(hipMemcpy(sample_rgb, ctx->sample_rgb.ptr, n_samples * 3 * sizeof(float), hipMemcpyDeviceToHost));
@@ -982,6 +1091,7 @@ int rtx_hit(RtxContext* ctx, uint32_t n, const float* origins, const float* dire
     a.directions = ctx->ray_d.ptr;
     a.hits = ctx->hits.ptr;
     if (mode == RTX_MODE_DETERMINISTIC) RTX_HIP(rtx_det_mode::launch_hit(a, nullptr));
+    else if (ctx->special.hit) RTX_HIP(launch_special_hit(ctx->special.hit, a, nullptr));
     else RTX_HIP(rtx_fast_mode::launch_hit(a, nullptr));
     RTX_HIP(hipDeviceSynchronize());
     RTX_HIP(hipMemcpy(hits, ctx->hits.ptr, (size_t)n * sizeof(RtxHit), hipMemcpyDeviceToHost));

@@ -1,0 +1,263 @@
+// rtx_special.cpp — scene-specialised scan kernels: source generation, run-time compilation, cache.
+#include "rtx_special.h"
+
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+
+extern "C" {
+extern const char rtx_src_core[];    // rtx_core.h    (rtx_sources.cpp)
+extern const char rtx_src_device[];  // rtx_device.h
+extern const char rtx_src_det[];     // include/rtx_det.h
+extern const char rtx_src_abi[];     // include/rtx.h
+}
+
+namespace rtxspecial {
+namespace {
+
+uint32_t bits(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, sizeof u);
+    return u;
+}
+
+void append(std::string& s, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+void append(std::string& s, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    s += buf;
+}
+
+// The HIP run-time compiler, taken from the process at first use (no link-time dependency: a
+// process without it renders through the table-driven kernels).
+struct Rtc {
+    using Program = void*;
+    int (*create)(Program*, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
+    int (*add_name)(Program, const char*) = nullptr;
+    int (*compile)(Program, int, const char* const*) = nullptr;
+    int (*log_size)(Program, size_t*) = nullptr;
+    int (*log)(Program, char*) = nullptr;
+    int (*lowered)(Program, const char*, const char**) = nullptr;
+    int (*code_size)(Program, size_t*) = nullptr;
+    int (*code)(Program, char*) = nullptr;
+    int (*destroy)(Program*) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+const Rtc& rtc() {
+    static Rtc r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = nullptr;
+        for (const char* name : {"libhiprtc.so.7", "libhiprtc.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) {
+            r.why = "the HIP run-time compiler (libhiprtc.so) is not available";
+            return;
+        }
+        auto sym = [&](const char* n) { return dlsym(h, n); };
+        r.create = reinterpret_cast<decltype(r.create)>(sym("hiprtcCreateProgram"));
+        r.add_name = reinterpret_cast<decltype(r.add_name)>(sym("hiprtcAddNameExpression"));
+        r.compile = reinterpret_cast<decltype(r.compile)>(sym("hiprtcCompileProgram"));
+        r.log_size = reinterpret_cast<decltype(r.log_size)>(sym("hiprtcGetProgramLogSize"));
+        r.log = reinterpret_cast<decltype(r.log)>(sym("hiprtcGetProgramLog"));
+        r.lowered = reinterpret_cast<decltype(r.lowered)>(sym("hiprtcGetLoweredName"));
+        r.code_size = reinterpret_cast<decltype(r.code_size)>(sym("hiprtcGetCodeSize"));
+        r.code = reinterpret_cast<decltype(r.code)>(sym("hiprtcGetCode"));
+        r.destroy = reinterpret_cast<decltype(r.destroy)>(sym("hiprtcDestroyProgram"));
+        r.ok = r.create && r.add_name && r.compile && r.log_size && r.log && r.lowered && r.code_size && r.code && r.destroy;
+        if (!r.ok) r.why = "libhiprtc.so lacks an entry point";
+    });
+    return r;
+}
+
+// The kernels compiled around a scan: what fast mode launches for a scene with a light list and a
+// constant background, and the ray query.
+constexpr int kKernels = 3;
+constexpr const char* kKernelExpr[kKernels] = {
+    "rtx_fast_mode::trace_kernel<false, false, false, true>",  // frames
+    "rtx_fast_mode::trace_kernel<false, true, false, true>",   // per-sample output
+    "rtx_fast_mode::hit_kernel<false>",                        // rtx_hit
+};
+
+struct CodeObject {
+    std::vector<char> image;
+    std::string kernel[kKernels];  // lowered names
+};
+std::mutex g_cache_mutex;
+std::map<std::string, std::shared_ptr<CodeObject>> g_cache;  // by scan text
+
+bool compile(const std::string& scan, CodeObject& out, std::string& why) {
+    const Rtc& r = rtc();
+    if (!r.ok) {
+        why = r.why;
+        return false;
+    }
+    // the translation unit: rtx_kernels_fast.hip's two lines with the scan in front
+    std::string src = "#define RTX_DET 0\n#define RTX_TRACE_WAVES 8\n#define RTX_SPECIAL_SCAN \\\n" + scan + "\n#include \"rtx_core.h\"\n";
+    const char* headers[] = {rtx_src_core, rtx_src_device, rtx_src_det, rtx_src_abi};
+    const char* names[] = {"rtx_core.h", "rtx_device.h", "rtx_det.h", "rtx.h"};
+    Rtc::Program prog = nullptr;
+    if (r.create(&prog, src.c_str(), "rtx_special.hip", 4, headers, names) != 0) {
+        why = "hiprtcCreateProgram failed";
+        return false;
+    }
+    bool ok = false;
+    do {
+        bool named = true;
+        for (const char* expr : kKernelExpr) named = named && r.add_name(prog, expr) == 0;
+        if (!named) {
+            why = "hiprtcAddNameExpression failed";
+            break;
+        }
+        // the flags of the fast-mode translation unit (csrc/Makefile: COMMON + FASTFLAGS)
+        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-ffp-contract=fast",
+                              "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-math-errno", "-fno-signed-zeros",
+                              "-fno-trapping-math", "-Wno-unused-function"};
+        if (r.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts) != 0) {
+            size_t n = 0;
+            r.log_size(prog, &n);
+            std::string log(n, '\0');
+            if (n) r.log(prog, &log[0]);
+            why = "run-time compilation failed: " + log.substr(0, 600);
+            break;
+        }
+        bool lowered_all = true;
+        for (int k = 0; k < kKernels; ++k) {
+            const char* lowered = nullptr;
+            if (r.lowered(prog, kKernelExpr[k], &lowered) != 0 || !lowered) {
+                lowered_all = false;
+                break;
+            }
+            out.kernel[k] = lowered;
+        }
+        if (!lowered_all) {
+            why = "hiprtcGetLoweredName failed";
+            break;
+        }
+        size_t n = 0;
+        if (r.code_size(prog, &n) != 0 || n == 0) {
+            why = "hiprtcGetCodeSize failed";
+            break;
+        }
+        out.image.resize(n);
+        if (r.code(prog, out.image.data()) != 0) {
+            why = "hiprtcGetCode failed";
+            break;
+        }
+        ok = true;
+    } while (false);
+    r.destroy(&prog);
+    return ok;
+}
+
+}  // namespace
+
+std::string scan_source(const std::vector<rtxd::ScanGroup>& groups, const std::vector<rtxd::ScanRec>& recs) {
+    std::string s;
+    for (const rtxd::ScanGroup& G : groups) {
+        s += "    { \\\n";
+        const float* m = G.m;
+        if (G.identity) {
+            s += "        RTX_SPECIAL_GROUP_IDENTITY(); \\\n";
+        } else if (G.rot_y) {
+            append(s, "        RTX_SPECIAL_GROUP_ROT_Y(0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu); \\\n", bits(m[0]), bits(m[2]),
+                   bits(m[6]), bits(m[8]), bits(m[9]), bits(m[10]), bits(m[11]));
+        } else {
+            s += "        RTX_SPECIAL_GROUP_AFFINE(";
+            for (int k = 0; k < 12; ++k) append(s, "0x%08xu%s", bits(m[k]), k < 11 ? ", " : "); \\\n");
+        }
+        uint32_t pos = G.first;
+        const struct { uint32_t n; const char* axes; } rects[3] = {{G.n_xy, "0, 1, 2"}, {G.n_xz, "0, 2, 1"}, {G.n_yz, "1, 2, 0"}};
+        for (const auto& kind : rects)
+            for (uint32_t k = 0; k < kind.n; ++k, ++pos) {
+                const rtxd::ScanRec& R = recs[pos];
+                append(s, "        RTX_SPECIAL_RECT(%s, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, %uu); \\\n", kind.axes, bits(R.a), bits(R.b),
+                       bits(R.c), bits(R.d), bits(R.e), pos);
+            }
+        if (G.n_sph) s += "        RTX_SPECIAL_SPHERES(); \\\n";
+        for (uint32_t k = 0; k < G.n_sph; ++k, ++pos) {
+            const rtxd::ScanRec& R = recs[pos];
+            append(s, "        RTX_SPECIAL_SPHERE(0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, %uu); \\\n", bits(R.a), bits(R.b), bits(R.c), bits(R.e), pos);
+        }
+        if (G.n_box) s += "        RTX_SPECIAL_BOXES(); \\\n";
+        for (uint32_t k = 0; k < G.n_box; ++k, pos += rtxd::kBoxSlots) {
+            const rtxd::ScanRec& R = recs[pos];
+            append(s, "        RTX_SPECIAL_BOX(0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, %uu); \\\n", bits(R.a), bits(R.b), bits(R.c),
+                   bits(R.d), bits(R.e), bits(R.f), pos);
+        }
+        s += "    } \\\n";
+    }
+    return s;
+}
+
+namespace {
+std::shared_ptr<CodeObject> cached_or_compiled(const std::string& scan, std::string& why, double* compile_seconds) {
+    if (compile_seconds) *compile_seconds = 0.0;
+    std::shared_ptr<CodeObject> code;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        auto it = g_cache.find(scan);
+        if (it != g_cache.end()) code = it->second;
+    }
+    if (!code) {
+        auto fresh = std::make_shared<CodeObject>();
+        const auto t0 = std::chrono::steady_clock::now();
+        if (!compile(scan, *fresh, why)) return nullptr;
+        if (compile_seconds) *compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        code = g_cache.emplace(scan, fresh).first->second;
+    }
+    return code;
+}
+}  // namespace
+
+bool prepare(const std::string& scan, std::string& why, double* compile_seconds) {
+    return cached_or_compiled(scan, why, compile_seconds) != nullptr;
+}
+
+bool load(const std::string& scan, Kernel& out, std::string& why, double* compile_seconds) {
+    const std::shared_ptr<CodeObject> code = cached_or_compiled(scan, why, compile_seconds);
+    if (!code) return false;
+    hipModule_t module = nullptr;
+    hipError_t e = hipModuleLoadData(&module, code->image.data());
+    if (e != hipSuccess) {
+        why = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+        return false;
+    }
+    hipFunction_t fn[kKernels] = {};
+    for (int k = 0; k < kKernels; ++k) {
+        e = hipModuleGetFunction(&fn[k], module, code->kernel[k].c_str());
+        if (e != hipSuccess) {
+            why = std::string("hipModuleGetFunction: ") + hipGetErrorString(e);
+            (void)hipGetLastError();
+            (void)hipModuleUnload(module);
+            return false;
+        }
+    }
+    out.module = module;
+    out.frames = fn[0];
+    out.samples = fn[1];
+    out.hit = fn[2];
+    return true;
+}
+
+void unload(Kernel& k) {
+    if (k.module) (void)hipModuleUnload(k.module);
+    k = Kernel{};
+}
+
+}  // namespace rtxspecial

@@ -1,0 +1,50 @@
+// rtx_special.h — scene-specialised scan kernels, compiled at scene upload (host side).
+//
+// The fast-mode linear scan walks a table of records with wave-uniform scalar loads; every record
+// field is then a scalar-register operand, which halves the issue rate of the vector instruction
+// that reads it, and every record costs a load, a wait and loop bookkeeping.  For a scene of a few
+// dozen primitives the table can be compiled into the kernel instead: rtx_upload_scene writes the
+// scan out as straight-line code with the records as literals and compiles the trace kernel around
+// it with the HIP run-time compiler.  The reference has nothing comparable (its scene is a tree of
+// virtual calls, ShapeList.cpp:5-17); this is the counterpart of building the scene into the binary.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+#include <vector>
+
+#include "rtx_device.h"
+
+namespace rtxspecial {
+
+// The kernels compiled for one scene, loaded on one device: the fast-mode trace kernel for frames
+// (trace_kernel<false, false, false, true>), the one with per-sample output
+// (trace_kernel<false, true, false, true>) and the ray query (hit_kernel<false>), so that a scene's
+// frames, samples and queries come from one and the same scan.
+struct Kernel {
+    hipModule_t module = nullptr;
+    hipFunction_t frames = nullptr, samples = nullptr, hit = nullptr;
+};
+
+// Primitive counts above which the scan is not specialised (the straight-line code of a long table
+// no longer fits the instruction cache; such scenes are rendered through the tree anyway).
+constexpr size_t kMaxRecords = 64;
+
+// The scan of the bucketed table (groups / recs as build_scan_table lays them out) as the text of
+// the RTX_SPECIAL_SCAN macro.
+std::string scan_source(const std::vector<rtxd::ScanGroup>& groups, const std::vector<rtxd::ScanRec>& recs);
+
+// Compiles the kernels (fast mode, a light list and a constant background) around `scan` for gfx950
+// and loads them on the current device.  Code objects are kept
+// per process and scan text, so a scene uploaded again - or on another device - is not compiled
+// twice.  Returns false with the reason in `why` (no run-time compiler in the process, compilation
+// failed, ...): the caller then keeps the table-driven kernel.
+bool load(const std::string& scan, Kernel& out, std::string& why, double* compile_seconds);
+
+// The compilation alone (no device needed): fills the process's cache so that a later load of the
+// same scan only loads the code object.
+bool prepare(const std::string& scan, std::string& why, double* compile_seconds);
+
+void unload(Kernel& k);
+
+}  // namespace rtxspecial

@@ -29,7 +29,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(api.RtxParams) == 40
     assert ctypes.sizeof(api.RtxHit) == 48
     assert api.HIT_DTYPE.itemsize == 48
-    assert ctypes.sizeof(api.RtxSceneInfo) == 24
+    assert ctypes.sizeof(api.RtxSceneInfo) == 32
     assert api.RtxScene.cam_origin.offset % 4 == 0
 
 
@@ -57,6 +57,31 @@ def test_struct_layout_matches_the_compiled_header(tmp_path):
             assert int(got[f"{name}.{field}"]) == getattr(cls, field).offset, (name, field)
     assert api.RTX_ABI_VERSION == int(re.search(r"#define RTX_ABI_VERSION (\d+)u", open(
         os.path.join(ROOT, "include", "rtx.h")).read()).group(1))
+
+
+def test_scene_kernels_compile_without_a_gpu():
+    """rtx_prepare_scene: the trace kernels around a small scene's scan, compiled by the HIP run-time
+    compiler from the sources inside librtx.so (the code path an upload takes, minus the device);
+    scenes the compiled variant does not cover are refused with the reason."""
+    import time
+
+    for name in ("cornell", "small", "bvh_stress_20"):
+        scene = api.HostScene(name, 32, 18)
+        t = time.time()
+        api.prepare_scene(scene)
+        first = time.time() - t
+        t = time.time()
+        api.prepare_scene(scene)  # from the process's cache
+        assert time.time() - t < 0.1 * max(first, 0.1)
+    for name in ("random_field", "sky_spheres", "cornell_light_tree"):
+        with pytest.raises(api.RtxError) as e:
+            api.prepare_scene(api.HostScene(name, 32, 18))
+        assert e.value.code == api.RTX_ERR_UNSUPPORTED and "specialised" in str(e.value)
+    bad = api.RtxScene.from_buffer_copy(api.HostScene("cornell", 8, 8).view)
+    bad.abi_version += 1
+    with pytest.raises(api.RtxError) as e:
+        api.prepare_scene(bad)
+    assert e.value.code == api.RTX_ERR_INVALID_ARGUMENT
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback():

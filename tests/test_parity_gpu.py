@@ -230,18 +230,138 @@ def test_fast_bvh_kernel_follows_the_paths_of_the_fast_scan(gpu_ctx, name, w, h,
     assert int(lin_seg.sum()) == lin_rays
 
 
+@pytest.mark.parametrize("specialize", [1, 0])
 @pytest.mark.parametrize("name", ["cornell", "cornell_classic", "small", "cornell_extra", "sky_spheres"])
-def test_fast_scan_frame_is_the_sum_of_its_samples(gpu_ctx, name):
+def test_fast_scan_frame_is_the_sum_of_its_samples(gpu_ctx, name, specialize):
     """The frame path of the fast linear-scan kernel (the benchmark's launch: the variant for a light
     list and a constant background, with the scene-bounds early-out) against its own per-sample
-    outputs: same paths (segment counts add up to the ray count), same radiance."""
+    outputs: same paths (segment counts add up to the ray count), same radiance.  With the scan
+    compiled for the scene at upload (the default) and with the table-driven kernels."""
     w, h, spp = 72, 40, 12
-    gpu_ctx.upload(api.HostScene(name, w, h), api.RTX_ACCEL_LINEAR)
-    p = gpu_ctx.params(w, h, 5, spp, mode=api.RTX_MODE_FAST, seed=17)
-    rgb, seg = gpu_ctx.render_samples(p)
-    frame, rays = gpu_ctx.render(p)
+    try:
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, specialize)
+        gpu_ctx.upload(api.HostScene(name, w, h), api.RTX_ACCEL_LINEAR)
+        assert gpu_ctx.info().scan_specialized == (1 if specialize and name != "sky_spheres" else 0), gpu_ctx.note()
+        p = gpu_ctx.params(w, h, 5, spp, mode=api.RTX_MODE_FAST, seed=17)
+        rgb, seg = gpu_ctx.render_samples(p)
+        frame, rays = gpu_ctx.render(p)
+    finally:
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 1)
     assert int(seg.sum()) == rays
     assert np.allclose(frame, rgb.reshape(h, w, spp, 3).sum(axis=2)[::-1], rtol=1e-4, atol=1e-5)
+
+
+def _tilted_cornell(w, h):
+    """The reference's Cornell box with its two boxes turned about a tilted axis instead of the y axis
+    (a transform whose composed map has no zero entry).  Returns the scene and what keeps its arrays alive."""
+    import ctypes as C
+
+    scene = api.HostScene("cornell", w, h)
+    v = api.RtxScene.from_buffer_copy(scene.view)
+    n = v.n_steps
+    cols = {k: (C.c_float * n)(*[getattr(v, k)[i] for i in range(n)]) for k in ("step_x", "step_y", "step_z", "step_w")}
+    axis = np.array([1.0, 2.0, 0.5]) / np.linalg.norm([1.0, 2.0, 0.5])
+    turned = 0
+    for i in range(n):
+        if v.step_kind[i] == api.RTX_STEP_ROTATE:
+            half = np.radians(20.0 if turned == 0 else -12.0) / 2
+            q = np.concatenate([axis * np.sin(half), [np.cos(half)]]).astype(np.float32)
+            cols["step_x"][i], cols["step_y"][i], cols["step_z"][i], cols["step_w"][i] = (float(c) for c in q)
+            turned += 1
+    assert turned >= 1
+    for k, col in cols.items():
+        setattr(v, k, C.cast(col, C.POINTER(C.c_float)))
+    return v, (scene, cols)
+
+
+@pytest.mark.parametrize("name,lo,hi", [("cornell", 0.0, 555.0), ("cornell_classic", 0.0, 555.0), ("cornell_extra", 0.0, 555.0),
+                                        ("textured", 0.0, 555.0), ("small", -8.0, 8.0), ("cornell_tilted", 0.0, 555.0),
+                                        # (negative coordinates, many transformed groups)
+                                        ("bvh_stress_20", 0.0, 100.0)])
+def test_scan_compiled_for_the_scene_agrees_with_the_table_scan(gpu_ctx, name, lo, hi):
+    """rtx_upload_scene compiles the scan of a small scene into the fast-mode kernels (records as
+    literals of straight-line code).  Against the table-driven kernels of the same library: the same
+    primitive wins a ray query except where two candidates lie within rounding of each other (the
+    compiler is free to contract a product with a literal differently from one with a register),
+    at the same distance; samples follow the same paths; the frame is the sum of its samples; and
+    the upload stays within two seconds, compilation included."""
+    import time
+
+    w, h, spp = 64, 36, 8
+    scene, keep = _tilted_cornell(w, h) if name == "cornell_tilted" else (api.HostScene(name, w, h), None)
+    rng = np.random.default_rng(5)
+    n = 200_000
+    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    if name == "small":
+        o[:, 1] = rng.uniform(0.05, 4.0, n)
+    if name == "bvh_stress_20":
+        o[:, 1] = rng.uniform(0.1, 25.0, n)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    p = gpu_ctx.params(w, h, 2, spp, mode=api.RTX_MODE_FAST, seed=23)
+    try:
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 0)
+        gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+        assert gpu_ctx.info().scan_specialized == 0 and "switched off" in gpu_ctx.note()
+        table_hits = gpu_ctx.hit(o, d, mode=api.RTX_MODE_FAST)
+        table_rgb, table_seg = gpu_ctx.render_samples(p)
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 1)
+        t = time.time()
+        gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+        seconds = time.time() - t
+        info = gpu_ctx.info()
+        assert info.scan_specialized == 1 and gpu_ctx.note() == "", gpu_ctx.note()
+        assert seconds < 2.0 and info.specialize_seconds <= seconds
+        hits = gpu_ctx.hit(o, d, mode=api.RTX_MODE_FAST)
+        rgb, seg = gpu_ctx.render_samples(p)
+        frame, rays = gpu_ctx.render(p)
+        # a second upload of the same scene finds the code object in the process's cache
+        gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+        assert gpu_ctx.info().scan_specialized == 1 and gpu_ctx.info().specialize_seconds == 0.0
+    finally:
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 1)
+    assert table_hits["hit"].mean() > 0.3
+    same = (hits["hit"] == table_hits["hit"]) & (hits["prim"] == table_hits["prim"])
+    assert same.mean() > 0.9995, same.mean()
+    m = same & (hits["hit"] == 1)
+    # (fp32 error of a hit point scales with the coordinates involved, not with t: the hit point itself
+    # or, for a sphere, its radius - the 1000-unit ground sphere of "small" cancels in Sphere.cpp:9-12)
+    a = (keep[0] if keep else scene).arrays()
+    big = float(np.max(a["prim_d"][a["prim_kind"] == 3], initial=1.0))
+    scale = np.maximum(np.abs(table_hits["p"][m]).max(axis=1), big)
+    dlen = np.linalg.norm(d[m], axis=1)
+    t_err = (np.abs(hits["t"][m] - table_hits["t"][m]) * dlen / scale).max()
+    p_err = (np.abs(hits["p"][m] - table_hits["p"][m]).max(axis=1) / scale).max()
+    assert t_err < 1e-4 and p_err < 1e-4, (t_err, p_err)
+    assert np.array_equal(hits["material"][m], table_hits["material"][m])
+    du = np.abs(hits["uv"][m] - table_hits["uv"][m])
+    du[:, 0] = np.minimum(du[:, 0], 1.0 - du[:, 0])  # (a sphere's u wraps at phi = +-pi)
+    # (asin of a pole's |y| one ulp above 1 is NaN, in the reference's Sphere.h:29-34 as well)
+    assert np.isnan(du).mean() < 1e-4 and np.nanmax(du) < 5e-3
+    # samples: the same paths but for the few that pass within rounding of an edge
+    same_path = seg == table_seg
+    allowed = max(2, int(0.005 * same_path.size))
+    assert (~same_path).sum() <= allowed, ((~same_path).sum(), same_path.size)
+    close = np.isclose(rgb, table_rgb, rtol=2e-2, atol=1e-3).all(axis=-1)
+    assert (~(close | ~same_path)).sum() <= allowed
+    assert abs(float(rgb.sum()) / float(table_rgb.sum()) - 1) < 2e-2
+    assert int(seg.sum()) == rays
+    assert np.allclose(frame, rgb.reshape(h, w, spp, 3).sum(axis=2)[::-1], rtol=1e-4, atol=1e-5)
+    del keep
+
+
+def test_scan_is_specialized_only_where_the_kernel_variant_applies(gpu_ctx):
+    """Scenes the compiled variant does not cover keep the table-driven kernels, silently where they
+    are no candidates (a sky background, a tree, a light tree) and with a note where they are too long."""
+    for name, accel in (("sky_spheres", api.RTX_ACCEL_LINEAR), ("cornell", api.RTX_ACCEL_BVH),
+                        ("cornell_light_tree", api.RTX_ACCEL_LINEAR), ("random_field", api.RTX_ACCEL_AUTO)):
+        gpu_ctx.upload(api.HostScene(name, 16, 9), accel)
+        assert gpu_ctx.info().scan_specialized == 0 and gpu_ctx.note() == "", (name, gpu_ctx.note())
+    gpu_ctx.upload(api.HostScene("bvh_stress_500", 16, 9), api.RTX_ACCEL_LINEAR)
+    assert gpu_ctx.info().scan_specialized == 0 and "scan records" in gpu_ctx.note()
+    with pytest.raises(api.RtxError):
+        gpu_ctx.set_option(99, 1)
+    with pytest.raises(api.RtxError):
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 2)
 
 
 def test_fast_mode_converges_to_cpu_ground_truth(gpu_ctx):
