@@ -104,7 +104,7 @@ RTX_SYMBOLS = (
     "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_device_count", "rtx_upload_scene",
     "rtx_render", "rtx_render_device", "rtx_render_samples", "rtx_hit", "rtx_resolve_device",
     "rtx_scene_info", "rtx_render_multi", "rtx_render_noalloc", "rtx_resolve_to_device",
-    "rtx_set_option", "rtx_prepare_scene", "rtx_scene_note",
+    "rtx_set_option", "rtx_prepare_scene", "rtx_scene_note", "rtx_scene_kernel_source",
 )
 RTX_NOALLOC_MAX_PIXELS = 1 << 21
 RTXH_SYMBOLS = (
@@ -185,10 +185,27 @@ def load_librtx() -> C.CDLL:
         lib.rtx_set_option.restype = C.c_int
         lib.rtx_prepare_scene.argtypes = [C.POINTER(RtxScene)]
         lib.rtx_prepare_scene.restype = C.c_int
+        lib.rtx_scene_kernel_source.argtypes = [C.POINTER(RtxScene), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        lib.rtx_scene_kernel_source.restype = C.c_int
         lib.rtx_scene_note.argtypes = [ctxp]
         lib.rtx_scene_note.restype = C.c_char_p
         _librtx = lib
     return _librtx
+
+
+def scene_kernel_source(scene) -> str:
+    """rtx_scene_kernel_source: the scan of the scene as generated for its specialised kernel."""
+    lib = load_librtx()
+    ptr = scene.view_ptr if isinstance(scene, HostScene) else C.pointer(scene)
+    needed = C.c_uint64(0)
+    rc = lib.rtx_scene_kernel_source(ptr, None, 0, C.byref(needed))
+    if rc != RTX_OK:
+        raise RtxError(rc, lib.rtx_last_error().decode())
+    buf = C.create_string_buffer(needed.value)
+    rc = lib.rtx_scene_kernel_source(ptr, buf, needed.value, None)
+    if rc != RTX_OK:
+        raise RtxError(rc, lib.rtx_last_error().decode())
+    return buf.value.decode()
 
 
 def prepare_scene(scene) -> None:

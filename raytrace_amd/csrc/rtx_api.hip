@@ -475,10 +475,12 @@ bool lights_need_tree(const RtxScene* s) {
     return with_density >= RTX_LIGHT_BVH_MIN;
 }
 
-// A scene whose fast-mode frames run trace_kernel<false, false, false, true>: a scan, a light list
-// without a tree, a constant background.
-bool scan_can_be_specialized(const RtxScene* s, bool use_bvh, bool light_tree) {
-    return !use_bvh && !light_tree && s->light_is_list && s->n_lights != 0 && s->background_mode != RTX_BACKGROUND_SKY;
+// The trace kernel variant rtx_fast_mode::launch_trace picks for the frames of a scan scene.
+rtxspecial::Variant scan_variant(const RtxScene* s, bool light_tree) {
+    rtxspecial::Variant v;
+    v.light_tree = light_tree;
+    v.list_lit = !light_tree && s->light_is_list && s->n_lights != 0 && s->background_mode != RTX_BACKGROUND_SKY;
+    return v;
 }
 
 // A trace kernel compiled for the uploaded scene: the launch rtx_fast_mode::launch_trace makes for a
@@ -628,11 +630,11 @@ int rtx_set_option(RtxContext* ctx, uint32_t option, uint64_t value) {
     return fail(RTX_ERR_INVALID_ARGUMENT, "unknown option or value");
 }
 
-int rtx_prepare_scene(const RtxScene* s) {
+// The scan text of a scene rtx_upload_scene would specialise (LINEAR or AUTO accel), or an error.
+static int special_scan_text(const RtxScene* s, std::string& scan) {
     int rc = check_scene(s);
     if (rc != RTX_OK) return rc;
-    if (s->n_prims > 64 || !scan_can_be_specialized(s, false, lights_need_tree(s)))
-        return fail(RTX_ERR_UNSUPPORTED, "not a scene whose scan is specialised (a scan of at most 64 primitives, a light list, a constant background)");
+    if (s->n_prims > 64) return fail(RTX_ERR_UNSUPPORTED, "not a scene whose scan is specialised (more than 64 primitives: rendered through the tree)");
     std::vector<rtxd::Prim> prims;
     std::vector<rtxd::Step> steps;
     std::vector<rtxd::Group> groups;
@@ -644,7 +646,28 @@ int rtx_prepare_scene(const RtxScene* s) {
     std::vector<uint32_t> scan_orig;
     build_scan_table(prims, prim_infos(s), groups, steps, scan_groups, scan_recs, scan_info, scan_orig);
     if (scan_recs.size() - 1 > rtxspecial::kMaxRecords) return fail(RTX_ERR_UNSUPPORTED, "more scan records than a specialised kernel takes");
-    if (!rtxspecial::prepare(rtxspecial::scan_source(scan_groups, scan_recs), err, nullptr)) return fail(RTX_ERR_UNSUPPORTED, err);
+    scan = rtxspecial::scan_source(scan_groups, scan_recs);
+    return RTX_OK;
+}
+
+int rtx_prepare_scene(const RtxScene* s) {
+    std::string scan, err;
+    int rc = special_scan_text(s, scan);
+    if (rc != RTX_OK) return rc;
+    if (!rtxspecial::prepare(scan, scan_variant(s, lights_need_tree(s)), err, nullptr)) return fail(RTX_ERR_UNSUPPORTED, err);
+    return RTX_OK;
+}
+
+int rtx_scene_kernel_source(const RtxScene* s, char* text, uint64_t capacity, uint64_t* needed) {
+    std::string scan;
+    int rc = special_scan_text(s, scan);
+    if (rc != RTX_OK) return rc;
+    if (needed) *needed = scan.size() + 1;
+    if (text && capacity) {
+        const size_t n = scan.size() < capacity - 1 ? scan.size() : capacity - 1;
+        std::memcpy(text, scan.data(), n);
+        text[n] = '\0';
+    }
     return RTX_OK;
 }
 
@@ -838,20 +861,20 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     ctx->info.accel = use_bvh ? RTX_ACCEL_BVH : RTX_ACCEL_LINEAR;
     ctx->info.bvh_depth = use_bvh ? (uint32_t)tree.depth : 0u;
     ctx->info.bvh_visits = use_bvh ? (float)tree.visits : 0.0f;
-    // the scan of a small scene compiled into the fast-mode trace kernel (the variant for a light list and a
-    // constant background: what launch_trace would pick for this scene's frames)
+    // the scan of a small scene compiled into the fast-mode trace kernel (the variant launch_trace would pick
+    // for this scene's frames)
     rtxspecial::unload(ctx->special);
     ctx->special_note.clear();
     ctx->info.scan_specialized = 0;
     ctx->info.specialize_seconds = 0.0f;
     if (light_tree != lights_need_tree(s)) return fail(RTX_ERR_HIP, "internal: light tree decision differs");
-    const bool candidate = scan_can_be_specialized(s, use_bvh, light_tree);
+    const bool candidate = !use_bvh;
     if (candidate && ctx->specialize_scan) {
         if (scan_recs.size() - 1 > rtxspecial::kMaxRecords) {
             ctx->special_note = "more than " + std::to_string(rtxspecial::kMaxRecords) + " scan records";
         } else {
             double seconds = 0.0;
-            if (rtxspecial::load(rtxspecial::scan_source(scan_groups, scan_recs), ctx->special, ctx->special_note, &seconds)) {
+            if (rtxspecial::load(rtxspecial::scan_source(scan_groups, scan_recs), scan_variant(s, light_tree), ctx->special, ctx->special_note, &seconds)) {
                 ctx->info.scan_specialized = 1;
                 ctx->info.specialize_seconds = (float)seconds;
             }

@@ -83,23 +83,23 @@ const Rtc& rtc() {
     return r;
 }
 
-// The kernels compiled around a scan: what fast mode launches for a scene with a light list and a
-// constant background, and the ray query.
+// The kernels compiled around a scan: the fast-mode trace kernel of the scene's variant for frames and
+// for per-sample output, and the ray query.
 constexpr int kKernels = 3;
-constexpr const char* kKernelExpr[kKernels] = {
-    "rtx_fast_mode::trace_kernel<false, false, false, true>",  // frames
-    "rtx_fast_mode::trace_kernel<false, true, false, true>",   // per-sample output
-    "rtx_fast_mode::hit_kernel<false>",                        // rtx_hit
-};
+std::string kernel_expr(int k, Variant v) {
+    if (k == 2) return "rtx_fast_mode::hit_kernel<false>";  // rtx_hit
+    return std::string("rtx_fast_mode::trace_kernel<false, ") + (k == 1 ? "true" : "false") + ", " + (v.light_tree ? "true" : "false") + ", " +
+           (v.list_lit ? "true" : "false") + ">";
+}
 
 struct CodeObject {
     std::vector<char> image;
     std::string kernel[kKernels];  // lowered names
 };
 std::mutex g_cache_mutex;
-std::map<std::string, std::shared_ptr<CodeObject>> g_cache;  // by scan text
+std::map<std::string, std::shared_ptr<CodeObject>> g_cache;  // by variant and scan text
 
-bool compile(const std::string& scan, CodeObject& out, std::string& why) {
+bool compile(const std::string& scan, Variant variant, CodeObject& out, std::string& why) {
     const Rtc& r = rtc();
     if (!r.ok) {
         why = r.why;
@@ -117,7 +117,7 @@ bool compile(const std::string& scan, CodeObject& out, std::string& why) {
     bool ok = false;
     do {
         bool named = true;
-        for (const char* expr : kKernelExpr) named = named && r.add_name(prog, expr) == 0;
+        for (int k = 0; k < kKernels; ++k) named = named && r.add_name(prog, kernel_expr(k, variant).c_str()) == 0;
         if (!named) {
             why = "hiprtcAddNameExpression failed";
             break;
@@ -137,7 +137,7 @@ bool compile(const std::string& scan, CodeObject& out, std::string& why) {
         bool lowered_all = true;
         for (int k = 0; k < kKernels; ++k) {
             const char* lowered = nullptr;
-            if (r.lowered(prog, kKernelExpr[k], &lowered) != 0 || !lowered) {
+            if (r.lowered(prog, kernel_expr(k, variant).c_str(), &lowered) != 0 || !lowered) {
                 lowered_all = false;
                 break;
             }
@@ -204,32 +204,33 @@ std::string scan_source(const std::vector<rtxd::ScanGroup>& groups, const std::v
 }
 
 namespace {
-std::shared_ptr<CodeObject> cached_or_compiled(const std::string& scan, std::string& why, double* compile_seconds) {
+std::shared_ptr<CodeObject> cached_or_compiled(const std::string& scan, Variant variant, std::string& why, double* compile_seconds) {
+    const std::string key = std::string(variant.light_tree ? "T" : "t") + (variant.list_lit ? "L" : "l") + scan;
     if (compile_seconds) *compile_seconds = 0.0;
     std::shared_ptr<CodeObject> code;
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
-        auto it = g_cache.find(scan);
+        auto it = g_cache.find(key);
         if (it != g_cache.end()) code = it->second;
     }
     if (!code) {
         auto fresh = std::make_shared<CodeObject>();
         const auto t0 = std::chrono::steady_clock::now();
-        if (!compile(scan, *fresh, why)) return nullptr;
+        if (!compile(scan, variant, *fresh, why)) return nullptr;
         if (compile_seconds) *compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::lock_guard<std::mutex> lock(g_cache_mutex);
-        code = g_cache.emplace(scan, fresh).first->second;
+        code = g_cache.emplace(key, fresh).first->second;
     }
     return code;
 }
 }  // namespace
 
-bool prepare(const std::string& scan, std::string& why, double* compile_seconds) {
-    return cached_or_compiled(scan, why, compile_seconds) != nullptr;
+bool prepare(const std::string& scan, Variant variant, std::string& why, double* compile_seconds) {
+    return cached_or_compiled(scan, variant, why, compile_seconds) != nullptr;
 }
 
-bool load(const std::string& scan, Kernel& out, std::string& why, double* compile_seconds) {
-    const std::shared_ptr<CodeObject> code = cached_or_compiled(scan, why, compile_seconds);
+bool load(const std::string& scan, Variant variant, Kernel& out, std::string& why, double* compile_seconds) {
+    const std::shared_ptr<CodeObject> code = cached_or_compiled(scan, variant, why, compile_seconds);
     if (!code) return false;
     hipModule_t module = nullptr;
     hipError_t e = hipModuleLoadData(&module, code->image.data());

@@ -17,9 +17,15 @@
 
 namespace rtxspecial {
 
+// Which trace kernel a scene's frames run (what rtx_fast_mode::launch_trace picks for a scan scene):
+// the one that walks a light tree, the one for a light list with a constant background, or the plain one.
+struct Variant {
+    bool light_tree = false, list_lit = false;
+};
+
 // The kernels compiled for one scene, loaded on one device: the fast-mode trace kernel for frames
-// (trace_kernel<false, false, false, true>), the one with per-sample output
-// (trace_kernel<false, true, false, true>) and the ray query (hit_kernel<false>), so that a scene's
+// (trace_kernel<false, false, light_tree, list_lit>), the one with per-sample output
+// (trace_kernel<false, true, ...>) and the ray query (hit_kernel<false>), so that a scene's
 // frames, samples and queries come from one and the same scan.
 struct Kernel {
     hipModule_t module = nullptr;
@@ -34,16 +40,15 @@ constexpr size_t kMaxRecords = 64;
 // the RTX_SPECIAL_SCAN macro.
 std::string scan_source(const std::vector<rtxd::ScanGroup>& groups, const std::vector<rtxd::ScanRec>& recs);
 
-// Compiles the kernels (fast mode, a light list and a constant background) around `scan` for gfx950
-// and loads them on the current device.  Code objects are kept
-// per process and scan text, so a scene uploaded again - or on another device - is not compiled
+// Compiles the kernels around `scan` for gfx950 and loads them on the current device.  Code objects are kept
+// per process, variant and scan text, so a scene uploaded again - or on another device - is not compiled
 // twice.  Returns false with the reason in `why` (no run-time compiler in the process, compilation
 // failed, ...): the caller then keeps the table-driven kernel.
-bool load(const std::string& scan, Kernel& out, std::string& why, double* compile_seconds);
+bool load(const std::string& scan, Variant variant, Kernel& out, std::string& why, double* compile_seconds);
 
 // The compilation alone (no device needed): fills the process's cache so that a later load of the
 // same scan only loads the code object.
-bool prepare(const std::string& scan, std::string& why, double* compile_seconds);
+bool prepare(const std::string& scan, Variant variant, std::string& why, double* compile_seconds);
 
 void unload(Kernel& k);
 

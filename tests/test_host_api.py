@@ -65,7 +65,8 @@ def test_scene_kernels_compile_without_a_gpu():
     scenes the compiled variant does not cover are refused with the reason."""
     import time
 
-    for name in ("cornell", "small", "bvh_stress_20"):
+    # (a light list, a sky background without lights, a light tree: the three kernel variants)
+    for name in ("cornell", "small", "bvh_stress_20", "sky_spheres", "cornell_light_tree"):
         scene = api.HostScene(name, 32, 18)
         t = time.time()
         api.prepare_scene(scene)
@@ -73,15 +74,44 @@ def test_scene_kernels_compile_without_a_gpu():
         t = time.time()
         api.prepare_scene(scene)  # from the process's cache
         assert time.time() - t < 0.1 * max(first, 0.1)
-    for name in ("random_field", "sky_spheres", "cornell_light_tree"):
-        with pytest.raises(api.RtxError) as e:
-            api.prepare_scene(api.HostScene(name, 32, 18))
-        assert e.value.code == api.RTX_ERR_UNSUPPORTED and "specialised" in str(e.value)
+    with pytest.raises(api.RtxError) as e:
+        api.prepare_scene(api.HostScene("random_field", 32, 18))
+    assert e.value.code == api.RTX_ERR_UNSUPPORTED and "specialised" in str(e.value)
     bad = api.RtxScene.from_buffer_copy(api.HostScene("cornell", 8, 8).view)
     bad.abi_version += 1
     with pytest.raises(api.RtxError) as e:
         api.prepare_scene(bad)
     assert e.value.code == api.RTX_ERR_INVALID_ARGUMENT
+
+
+def test_generated_scan_lists_every_primitive_of_the_scene_once():
+    """rtx_scene_kernel_source: the reference's Cornell box (Scene.cpp:43-86) as generated code - one
+    line per record, the positions 0 .. n-1 in order, coordinates as the bits of the scene's floats."""
+    scene = api.HostScene("cornell", 32, 18)
+    text = api.scene_kernel_source(scene)
+    a = scene.arrays()
+    rects = re.findall(r"RTX_SPECIAL_RECT\((\d), (\d), (\d), (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (\d+)u\)", text)
+    spheres = re.findall(r"RTX_SPECIAL_SPHERE\((0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (\d+)u\)", text)
+    boxes = re.findall(r"RTX_SPECIAL_BOX\(.*?, (\d+)u\)", text)
+    kinds = a["prim_kind"]
+    assert len(spheres) == (kinds == api.RTX_PRIM_SPHERE).sum()
+    assert len(rects) + 6 * len(boxes) == (kinds != api.RTX_PRIM_SPHERE).sum()
+    positions = sorted([int(r[-1]) for r in rects] + [int(s[-1]) for s in spheres] + [int(b) for b in boxes])
+    expect, pos = [], 0
+    for _ in range(len(rects) + len(spheres)):
+        expect.append(pos)
+        pos += 1
+    for _ in boxes:
+        expect.append(pos)
+        pos += 6
+    assert positions == expect
+    as_float = lambda h: np.array([int(h, 16)], np.uint32).view(np.float32)[0]
+    # the light of the reference's scene: Rect XZ 213..343 x 227..332 at y = 554 (Scene.cpp:63-67)
+    assert any((as_float(r[3]), as_float(r[4]), as_float(r[5]), as_float(r[6]), as_float(r[7])) == (213.0, 343.0, 227.0, 332.0, 554.0)
+               and r[:3] == ("0", "2", "1") for r in rects)
+    radii = sorted(float(np.sqrt(as_float(s[3]))) for s in spheres)
+    assert radii == sorted(float(v) for v in a["prim_d"][kinds == api.RTX_PRIM_SPHERE])
+    assert text.count("RTX_SPECIAL_GROUP_") == text.count("    { \\\n")
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback():

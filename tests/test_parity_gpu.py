@@ -241,7 +241,7 @@ def test_fast_scan_frame_is_the_sum_of_its_samples(gpu_ctx, name, specialize):
     try:
         gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, specialize)
         gpu_ctx.upload(api.HostScene(name, w, h), api.RTX_ACCEL_LINEAR)
-        assert gpu_ctx.info().scan_specialized == (1 if specialize and name != "sky_spheres" else 0), gpu_ctx.note()
+        assert gpu_ctx.info().scan_specialized == specialize, gpu_ctx.note()
         p = gpu_ctx.params(w, h, 5, spp, mode=api.RTX_MODE_FAST, seed=17)
         rgb, seg = gpu_ctx.render_samples(p)
         frame, rays = gpu_ctx.render(p)
@@ -277,7 +277,10 @@ def _tilted_cornell(w, h):
 @pytest.mark.parametrize("name,lo,hi", [("cornell", 0.0, 555.0), ("cornell_classic", 0.0, 555.0), ("cornell_extra", 0.0, 555.0),
                                         ("textured", 0.0, 555.0), ("small", -8.0, 8.0), ("cornell_tilted", 0.0, 555.0),
                                         # (negative coordinates, many transformed groups)
-                                        ("bvh_stress_20", 0.0, 100.0)])
+                                        ("bvh_stress_20", 0.0, 100.0),
+                                        # (the kernel variants without a light list / with a light tree)
+                                        ("sky_spheres", -8.0, 8.0), ("cornell_light_tree", 0.0, 555.0),
+                                        ("cornell_side_lights", 0.0, 555.0)])
 def test_scan_compiled_for_the_scene_agrees_with_the_table_scan(gpu_ctx, name, lo, hi):
     """rtx_upload_scene compiles the scan of a small scene into the fast-mode kernels (records as
     literals of straight-line code).  Against the table-driven kernels of the same library: the same
@@ -292,7 +295,7 @@ def test_scan_compiled_for_the_scene_agrees_with_the_table_scan(gpu_ctx, name, l
     rng = np.random.default_rng(5)
     n = 200_000
     o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
-    if name == "small":
+    if name in ("small", "sky_spheres"):
         o[:, 1] = rng.uniform(0.05, 4.0, n)
     if name == "bvh_stress_20":
         o[:, 1] = rng.uniform(0.1, 25.0, n)
@@ -349,11 +352,10 @@ def test_scan_compiled_for_the_scene_agrees_with_the_table_scan(gpu_ctx, name, l
     del keep
 
 
-def test_scan_is_specialized_only_where_the_kernel_variant_applies(gpu_ctx):
-    """Scenes the compiled variant does not cover keep the table-driven kernels, silently where they
-    are no candidates (a sky background, a tree, a light tree) and with a note where they are too long."""
-    for name, accel in (("sky_spheres", api.RTX_ACCEL_LINEAR), ("cornell", api.RTX_ACCEL_BVH),
-                        ("cornell_light_tree", api.RTX_ACCEL_LINEAR), ("random_field", api.RTX_ACCEL_AUTO)):
+def test_scan_is_specialized_only_for_scans_of_at_most_64_records(gpu_ctx):
+    """Scenes rendered through the tree keep their kernels silently; a scan that is too long for
+    straight-line code keeps the table-driven kernels with a note."""
+    for name, accel in (("cornell", api.RTX_ACCEL_BVH), ("random_field", api.RTX_ACCEL_AUTO)):
         gpu_ctx.upload(api.HostScene(name, 16, 9), accel)
         assert gpu_ctx.info().scan_specialized == 0 and gpu_ctx.note() == "", (name, gpu_ctx.note())
     gpu_ctx.upload(api.HostScene("bvh_stress_500", 16, 9), api.RTX_ACCEL_LINEAR)
