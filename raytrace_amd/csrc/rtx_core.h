@@ -579,7 +579,12 @@ RTX_DEV void scan_boxes(const SceneView& sc, uint32_t& pos, uint32_t count, V3 r
 // load, a wait and the loop's bookkeeping (Cornell box: 104.7 -> 114.4 Grays/s).  Arguments are the bits
 // of the fp32 values.
 #define RTX_SPECIAL_F(bits) __builtin_bit_cast(float, (uint32_t)(bits))
-#define RTX_SPECIAL_RECT(XI, YI, ZI, X0, X1, Y0, Y1, K, POS)                                                        \
+// lo <= v <= hi as two v_cmpx, and for lo == +0 and hi > 0 as one: the bits of a float in [0, hi] are, read
+// as an unsigned integer, at most those of hi, and those of a negative number or a NaN are above them
+// (only -0.0 ends up on the other side of the test)
+#define RTX_SPECIAL_RANGE(LO, HI, V) "v_cmpx_le_f32 vcc, %[" LO "], %[" V "]\n\tv_cmpx_ge_f32 vcc, %[" HI "], %[" V "]\n\t"
+#define RTX_SPECIAL_RANGE0(LO, HI, V) "v_cmpx_ge_u32 vcc, %[" HI "], %[" V "]\n\t"
+#define RTX_SPECIAL_RECT(XI, YI, ZI, XR, YR, X0, X1, Y0, Y1, K, POS)                                                \
     do {                                                                                                             \
         float t_, x_, y_;                                                                                            \
         unsigned long long saved_;                                                                                   \
@@ -589,10 +594,7 @@ RTX_DEV void scan_boxes(const SceneView& sc, uint32_t& pos, uint32_t count, V3 r
             "s_mov_b64 %[saved], exec\n\t"                                                                           \
             "v_cmpx_le_f32 vcc, 0x3a83126f, %[t]\n\t" /* kTMin */                                                    \
             "v_cmpx_ge_f32 vcc, %[closest], %[t]\n\t"                                                                \
-            "v_cmpx_le_f32 vcc, %[x0], %[x]\n\t"                                                                     \
-            "v_cmpx_ge_f32 vcc, %[x1], %[x]\n\t"                                                                     \
-            "v_cmpx_le_f32 vcc, %[y0], %[y]\n\t"                                                                     \
-            "v_cmpx_ge_f32 vcc, %[y1], %[y]\n\t"                                                                     \
+            XR("x0", "x1", "x") YR("y0", "y1", "y")                                                                  \
             "v_mov_b32 %[closest], %[t]\n\t"                                                                         \
             "v_mov_b32 %[best], %[pos]\n\t"                                                                          \
             "s_mov_b64 exec, %[saved]"                                                                               \
@@ -636,11 +638,13 @@ RTX_DEV void scan_boxes(const SceneView& sc, uint32_t& pos, uint32_t count, V3 r
     const V3 binv_ = v3(__builtin_amdgcn_fmed3f(aux_.inv_d.x, -1.0e30f, 1.0e30f), __builtin_amdgcn_fmed3f(aux_.inv_d.y, -1.0e30f, 1.0e30f), \
                         __builtin_amdgcn_fmed3f(aux_.inv_d.z, -1.0e30f, 1.0e30f));                                   \
     const V3 bnoi_ = v3(-ro_.x * binv_.x, -ro_.y * binv_.y, -ro_.z * binv_.z)
+// (a plane at coordinate +0: 0 * binv_ is 0 because binv_ is finite, the distance is bnoi_ itself)
+#define RTX_SPECIAL_PLANE(K, INV, NOI) ((uint32_t)(K) == 0u ? (NOI) : __builtin_fmaf(RTX_SPECIAL_F(K), INV, NOI))
 #define RTX_SPECIAL_BOX(LX, LY, LZ, HX, HY, HZ, POS)                                                                 \
     do { /* as scan_boxes */                                                                                         \
-        const float lx = __builtin_fmaf(RTX_SPECIAL_F(LX), binv_.x, bnoi_.x), hx = __builtin_fmaf(RTX_SPECIAL_F(HX), binv_.x, bnoi_.x); \
-        const float ly = __builtin_fmaf(RTX_SPECIAL_F(LY), binv_.y, bnoi_.y), hy = __builtin_fmaf(RTX_SPECIAL_F(HY), binv_.y, bnoi_.y); \
-        const float lz = __builtin_fmaf(RTX_SPECIAL_F(LZ), binv_.z, bnoi_.z), hz = __builtin_fmaf(RTX_SPECIAL_F(HZ), binv_.z, bnoi_.z); \
+        const float lx = RTX_SPECIAL_PLANE(LX, binv_.x, bnoi_.x), hx = RTX_SPECIAL_PLANE(HX, binv_.x, bnoi_.x);        \
+        const float ly = RTX_SPECIAL_PLANE(LY, binv_.y, bnoi_.y), hy = RTX_SPECIAL_PLANE(HY, binv_.y, bnoi_.y);        \
+        const float lz = RTX_SPECIAL_PLANE(LZ, binv_.z, bnoi_.z), hz = RTX_SPECIAL_PLANE(HZ, binv_.z, bnoi_.z);        \
         const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx, hx), __builtin_fminf(ly, hy)), __builtin_fminf(lz, hz)); \
         const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx, hx), __builtin_fmaxf(ly, hy)), __builtin_fmaxf(lz, hz)); \
         const float t = tn >= t0_ ? tn : tf;                                                                         \
@@ -662,7 +666,7 @@ RTX_DEV bool query_linear(const SceneView& sc, V3 o, V3 d, float t0, float t1, f
     static_assert(__builtin_bit_cast(uint32_t, kTMin) == 0x3a83126fu, "the literal in RTX_SPECIAL_RECT");
     if (t0 == kTMin) {  // (what the trace kernels ask; the comparison folds away once the call is inlined)
         const V3 o_ = o, d_ = d;
-        const float t0_ = t0;
+        constexpr float t0_ = kTMin;  // (a constant for the compiler, not the register that compared equal to it)
         float closest_ = closest;
         uint32_t best_ = best;
         RTX_SPECIAL_SCAN

@@ -184,8 +184,11 @@ std::string scan_source(const std::vector<rtxd::ScanGroup>& groups, const std::v
         for (const auto& kind : rects)
             for (uint32_t k = 0; k < kind.n; ++k, ++pos) {
                 const rtxd::ScanRec& R = recs[pos];
-                append(s, "        RTX_SPECIAL_RECT(%s, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, %uu); \\\n", kind.axes, bits(R.a), bits(R.b),
-                       bits(R.c), bits(R.d), bits(R.e), pos);
+                // (an interval that starts at +0 and ends above it is one unsigned comparison)
+                const char* xr = bits(R.a) == 0u && R.b > 0.0f ? "RTX_SPECIAL_RANGE0" : "RTX_SPECIAL_RANGE";
+                const char* yr = bits(R.c) == 0u && R.d > 0.0f ? "RTX_SPECIAL_RANGE0" : "RTX_SPECIAL_RANGE";
+                append(s, "        RTX_SPECIAL_RECT(%s, %s, %s, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, %uu); \\\n", kind.axes, xr, yr,
+                       bits(R.a), bits(R.b), bits(R.c), bits(R.d), bits(R.e), pos);
             }
         if (G.n_sph) s += "        RTX_SPECIAL_SPHERES(); \\\n";
         for (uint32_t k = 0; k < G.n_sph; ++k, ++pos) {

@@ -90,7 +90,7 @@ def test_generated_scan_lists_every_primitive_of_the_scene_once():
     scene = api.HostScene("cornell", 32, 18)
     text = api.scene_kernel_source(scene)
     a = scene.arrays()
-    rects = re.findall(r"RTX_SPECIAL_RECT\((\d), (\d), (\d), (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (\d+)u\)", text)
+    rects = re.findall(r"RTX_SPECIAL_RECT\((\d), (\d), (\d), RTX_SPECIAL_RANGE0?, RTX_SPECIAL_RANGE0?, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (\d+)u\)", text)
     spheres = re.findall(r"RTX_SPECIAL_SPHERE\((0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (0x[0-9a-f]{8})u, (\d+)u\)", text)
     boxes = re.findall(r"RTX_SPECIAL_BOX\(.*?, (\d+)u\)", text)
     kinds = a["prim_kind"]
@@ -112,6 +112,8 @@ def test_generated_scan_lists_every_primitive_of_the_scene_once():
     radii = sorted(float(np.sqrt(as_float(s[3]))) for s in spheres)
     assert radii == sorted(float(v) for v in a["prim_d"][kinds == api.RTX_PRIM_SPHERE])
     assert text.count("RTX_SPECIAL_GROUP_") == text.count("    { \\\n")
+    # the walls span 0 .. 555: their interval tests are the single unsigned comparison
+    assert text.count("RTX_SPECIAL_RANGE0, RTX_SPECIAL_RANGE0") == 5
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback():
