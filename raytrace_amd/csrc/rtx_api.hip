@@ -475,6 +475,29 @@ bool lights_need_tree(const RtxScene* s) {
     return with_density >= RTX_LIGHT_BVH_MIN;
 }
 
+// Entry l of the scene's light arrays as the kernels read it.
+rtxd::Light light_record(const RtxScene* s, uint32_t l) {
+    rtxd::Light E;
+    E.a = s->light_a[l]; E.b = s->light_b[l]; E.c = s->light_c[l]; E.d = s->light_d[l]; E.e = s->light_e[l];
+    E.kind = s->light_kind[l];
+    E.inv_area = E.kind <= RTX_LIGHT_RECT_YZ ? 1.0f / ((E.b - E.a) * (E.d - E.c)) : 0.0f;
+    E.pad = 0;
+    return E;
+}
+
+// The text of the kernels compiled for a scan scene: the scan and, where the density sum of a diffuse
+// bounce runs over a plain list (no light tree), the light entries.
+std::string special_text(const RtxScene* s, bool light_tree, const std::vector<rtxd::ScanGroup>& scan_groups,
+                         const std::vector<rtxd::ScanRec>& scan_recs) {
+    std::string text = rtxspecial::scan_source(scan_groups, scan_recs);
+    if (!light_tree && s->n_lights != 0) {
+        std::vector<rtxd::Light> lights(s->n_lights);
+        for (uint32_t l = 0; l < s->n_lights; ++l) lights[l] = light_record(s, l);
+        text += rtxspecial::lights_source(lights, s->n_lights, s->light_is_list != 0);
+    }
+    return text;
+}
+
 // The trace kernel variant rtx_fast_mode::launch_trace picks for the frames of a scan scene.
 rtxspecial::Variant scan_variant(const RtxScene* s, bool light_tree) {
     rtxspecial::Variant v;
@@ -646,7 +669,7 @@ static int special_scan_text(const RtxScene* s, std::string& scan) {
     std::vector<uint32_t> scan_orig;
     build_scan_table(prims, prim_infos(s), groups, steps, scan_groups, scan_recs, scan_info, scan_orig);
     if (scan_recs.size() - 1 > rtxspecial::kMaxRecords) return fail(RTX_ERR_UNSUPPORTED, "more scan records than a specialised kernel takes");
-    scan = rtxspecial::scan_source(scan_groups, scan_recs);
+    scan = special_text(s, lights_need_tree(s), scan_groups, scan_recs);
     return RTX_OK;
 }
 
@@ -710,10 +733,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     bool light_tree = false;
     for (uint32_t l = 0; l < n_light_entries; ++l) {
         rtxd::Light& E = lights[l];
-        E.a = s->light_a[l]; E.b = s->light_b[l]; E.c = s->light_c[l]; E.d = s->light_d[l]; E.e = s->light_e[l];
-        E.kind = s->light_kind[l];
-        E.inv_area = E.kind <= RTX_LIGHT_RECT_YZ ? 1.0f / ((E.b - E.a) * (E.d - E.c)) : 0.0f;
-        E.pad = 0;
+        E = light_record(s, l);
         rtxd::LightNode& N = light_nodes[l];  // value-initialised; a nested entry's weight is already set by its list
         // ShapeList::pdf_value weighs each entry by 1.0f / size (ShapeList.cpp:20); nested lists multiply
         if (l < s->n_lights) N.weight = s->light_is_list ? 1.0f / (float)s->n_lights : 1.0f;
@@ -874,7 +894,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
             ctx->special_note = "more than " + std::to_string(rtxspecial::kMaxRecords) + " scan records";
         } else {
             double seconds = 0.0;
-            if (rtxspecial::load(rtxspecial::scan_source(scan_groups, scan_recs), scan_variant(s, light_tree), ctx->special, ctx->special_note, &seconds)) {
+            if (rtxspecial::load(special_text(s, light_tree, scan_groups, scan_recs), scan_variant(s, light_tree), ctx->special, ctx->special_note, &seconds)) {
                 ctx->info.scan_specialized = 1;
                 ctx->info.specialize_seconds = (float)seconds;
             }

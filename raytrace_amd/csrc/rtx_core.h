@@ -1260,6 +1260,23 @@ RTX_DEV float light_pdf_one_fast(const Light& E, V3 o, V3 v, float len2, float i
 
 template <bool kListLit = false>
 RTX_DEV float light_pdf_fast(const SceneView& sc, V3 o, V3 v, float len2, float inv_len) {
+#ifdef RTX_SPECIAL_LIGHTS
+    // the light entries of the scene this kernel was compiled for, as literals (rtx_special.cpp): the
+    // sum below in straight-line code, each entry's kind resolved at compile time
+    {
+        float sum_ = 0.0f;
+#define RTX_SPECIAL_LIGHT(KIND, A, B, C, D, E, INV_AREA)                                                             \
+    do {                                                                                                             \
+        Light E_;                                                                                                    \
+        E_.a = RTX_SPECIAL_F(A); E_.b = RTX_SPECIAL_F(B); E_.c = RTX_SPECIAL_F(C); E_.d = RTX_SPECIAL_F(D);          \
+        E_.e = RTX_SPECIAL_F(E); E_.kind = (KIND); E_.inv_area = RTX_SPECIAL_F(INV_AREA); E_.pad = 0u;               \
+        sum_ += light_pdf_one_fast(E_, o, v, len2, inv_len);                                                         \
+    } while (0)
+        RTX_SPECIAL_LIGHTS
+#undef RTX_SPECIAL_LIGHT
+        return sum_ * RTX_SPECIAL_F(RTX_SPECIAL_LIGHT_WEIGHT);
+    }
+#endif
     if (!kListLit && !sc.light_is_list) return light_pdf_one_fast(load_uniform(sc.lights, 0u), o, v, len2, inv_len);
     float sum = 0.0f;
     if (kListLit) {  // at least one entry: no test before the first turn (and no register for its outcome)

@@ -106,7 +106,11 @@ bool compile(const std::string& scan, Variant variant, CodeObject& out, std::str
         return false;
     }
     // the translation unit: rtx_kernels_fast.hip's two lines with the scan in front
-    std::string src = "#define RTX_DET 0\n#define RTX_TRACE_WAVES 8\n#define RTX_SPECIAL_SCAN \\\n" + scan + "\n#include \"rtx_core.h\"\n";
+    std::string src = "#define RTX_DET 0\n#define RTX_TRACE_WAVES 8\n";
+#ifdef RTX_VARIANT_DEFINES  // (experiment builds, tools/build_variant.sh: the defines of the variant's own fast-mode kernels)
+    src += RTX_VARIANT_DEFINES;
+#endif
+    src += scan + "#include \"rtx_core.h\"\n";
     const char* headers[] = {rtx_src_core, rtx_src_device, rtx_src_det, rtx_src_abi};
     const char* names[] = {"rtx_core.h", "rtx_device.h", "rtx_det.h", "rtx.h"};
     Rtc::Program prog = nullptr;
@@ -165,8 +169,21 @@ bool compile(const std::string& scan, Variant variant, CodeObject& out, std::str
 
 }  // namespace
 
+std::string lights_source(const std::vector<rtxd::Light>& lights, uint32_t n_lights, bool is_list) {
+    if (n_lights == 0u || n_lights > kMaxRecords) return std::string();
+    std::string s = "#define RTX_SPECIAL_LIGHTS \\\n";
+    for (uint32_t l = 0; l < n_lights; ++l) {
+        const rtxd::Light& E = lights[l];
+        append(s, "    RTX_SPECIAL_LIGHT(%uu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu); \\\n", E.kind, bits(E.a), bits(E.b), bits(E.c),
+               bits(E.d), bits(E.e), bits(E.inv_area));
+    }
+    // ShapeList::pdf_value weighs each entry by 1 / size (ShapeList.cpp:20); a bare shape counts whole
+    append(s, "\n#define RTX_SPECIAL_LIGHT_WEIGHT 0x%08xu\n", bits(is_list ? 1.0f / (float)n_lights : 1.0f));
+    return s;
+}
+
 std::string scan_source(const std::vector<rtxd::ScanGroup>& groups, const std::vector<rtxd::ScanRec>& recs) {
-    std::string s;
+    std::string s = "#define RTX_SPECIAL_SCAN \\\n";
     for (const rtxd::ScanGroup& G : groups) {
         s += "    { \\\n";
         const float* m = G.m;
@@ -203,6 +220,7 @@ std::string scan_source(const std::vector<rtxd::ScanGroup>& groups, const std::v
         }
         s += "    } \\\n";
     }
+    s += "\n";
     return s;
 }
 

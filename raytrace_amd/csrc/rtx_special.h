@@ -36,19 +36,25 @@ struct Kernel {
 // no longer fits the instruction cache; such scenes are rendered through the tree anyway).
 constexpr size_t kMaxRecords = 64;
 
-// The scan of the bucketed table (groups / recs as build_scan_table lays them out) as the text of
-// the RTX_SPECIAL_SCAN macro.
+// The scan of the bucketed table (groups / recs as build_scan_table lays them out) as the definition
+// of the RTX_SPECIAL_SCAN macro.
 std::string scan_source(const std::vector<rtxd::ScanGroup>& groups, const std::vector<rtxd::ScanRec>& recs);
+
+// The top-level entries of a light list without a tree (or the one bare light shape) as the
+// definition of RTX_SPECIAL_LIGHTS / RTX_SPECIAL_LIGHT_WEIGHT: the density sum of a diffuse bounce
+// (ShapeList.cpp:19-26) then runs over literals instead of scalar-loaded records.  Empty for scenes
+// without lights or with more than kMaxRecords of them.  A kernel's text is scan_source + lights_source.
+std::string lights_source(const std::vector<rtxd::Light>& lights, uint32_t n_lights, bool is_list);
 
 // Compiles the kernels around `scan` for gfx950 and loads them on the current device.  Code objects are kept
 // per process, variant and scan text, so a scene uploaded again - or on another device - is not compiled
 // twice.  Returns false with the reason in `why` (no run-time compiler in the process, compilation
 // failed, ...): the caller then keeps the table-driven kernel.
-bool load(const std::string& scan, Variant variant, Kernel& out, std::string& why, double* compile_seconds);
+bool load(const std::string& text, Variant variant, Kernel& out, std::string& why, double* compile_seconds);
 
 // The compilation alone (no device needed): fills the process's cache so that a later load of the
 // same scan only loads the code object.
-bool prepare(const std::string& scan, Variant variant, std::string& why, double* compile_seconds);
+bool prepare(const std::string& text, Variant variant, std::string& why, double* compile_seconds);
 
 void unload(Kernel& k);
 

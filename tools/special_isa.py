@@ -22,7 +22,7 @@ def main():
     scan = api.scene_kernel_source(api.HostScene(name, 64, 64))
     src = os.path.join(out, name + ".hip")
     with open(src, "w") as f:
-        f.write("#define RTX_DET 0\n#define RTX_TRACE_WAVES 8\n#define RTX_SPECIAL_SCAN \\\n" + scan + "\n#include \"rtx_core.h\"\n"
+        f.write("#define RTX_DET 0\n#define RTX_TRACE_WAVES 8\n" + scan + "#include \"rtx_core.h\"\n"
                 "template __global__ void rtx_fast_mode::trace_kernel<false, false, false, true>(const rtxd::TraceArgs);\n")
     asm = os.path.join(out, name + ".s")
     cmd = ["hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-Iraytrace_amd/csrc", "-Iinclude", *FASTFLAGS, src, "-o", asm]
