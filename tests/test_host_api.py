@@ -84,6 +84,20 @@ def test_scene_kernels_compile_without_a_gpu():
     assert e.value.code == api.RTX_ERR_INVALID_ARGUMENT
 
 
+def test_a_scan_that_does_not_compile_is_refused_with_the_compilers_message(tmp_path):
+    """The failure path of the run-time compilation (tests/special_check.cpp, host only): rtx_upload_scene
+    keeps the table-driven kernels when it returns false."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "raytrace_amd", "csrc")
+    exe = str(tmp_path / "special_check")
+    subprocess.run(["hipcc", "-std=c++17", "-O1", "-x", "hip", "--offload-arch=gfx950", "-I" + csrc, "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "special_check.cpp"), os.path.join(csrc, "rtx_special.cpp"), "-x", "none",
+                    os.path.join(csrc, "build", "rtx_sources.o"), "-ldl", "-o", exe], check=True, capture_output=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
 def test_generated_scan_lists_every_primitive_of_the_scene_once():
     """rtx_scene_kernel_source: the reference's Cornell box (Scene.cpp:43-86) as generated code - one
     line per record, the positions 0 .. n-1 in order, coordinates as the bits of the scene's floats."""
