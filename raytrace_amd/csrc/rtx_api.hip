@@ -488,13 +488,12 @@ rtxd::Light light_record(const RtxScene* s, uint32_t l) {
 // The text of the kernels compiled for a scan scene: the scan and, where the density sum of a diffuse
 // bounce runs over a plain list (no light tree), the light entries.
 std::string special_text(const RtxScene* s, bool light_tree, const std::vector<rtxd::ScanGroup>& scan_groups,
-                         const std::vector<rtxd::ScanRec>& scan_recs) {
-    std::string text = rtxspecial::scan_source(scan_groups, scan_recs);
-    if (!light_tree && s->n_lights != 0) {
-        std::vector<rtxd::Light> lights(s->n_lights);
-        for (uint32_t l = 0; l < s->n_lights; ++l) lights[l] = light_record(s, l);
-        text += rtxspecial::lights_source(lights, s->n_lights, s->light_is_list != 0);
-    }
+                         const std::vector<rtxd::ScanRec>& scan_recs, const std::vector<rtxd::ScanHit>& scan_hits) {
+    std::vector<rtxd::Light> lights(s->n_lights);
+    for (uint32_t l = 0; l < s->n_lights; ++l) lights[l] = light_record(s, l);
+    std::string text = rtxspecial::features_source(scan_hits, lights, s->n_lights, light_tree);
+    text += rtxspecial::scan_source(scan_groups, scan_recs);
+    if (!light_tree && s->n_lights != 0) text += rtxspecial::lights_source(lights, s->n_lights, s->light_is_list != 0);
     return text;
 }
 
@@ -669,7 +668,7 @@ static int special_scan_text(const RtxScene* s, std::string& scan) {
     std::vector<uint32_t> scan_orig;
     build_scan_table(prims, prim_infos(s), groups, steps, scan_groups, scan_recs, scan_info, scan_orig);
     if (scan_recs.size() - 1 > rtxspecial::kMaxRecords) return fail(RTX_ERR_UNSUPPORTED, "more scan records than a specialised kernel takes");
-    scan = special_text(s, lights_need_tree(s), scan_groups, scan_recs);
+    scan = special_text(s, lights_need_tree(s), scan_groups, scan_recs, scan_info);
     return RTX_OK;
 }
 
@@ -894,7 +893,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
             ctx->special_note = "more than " + std::to_string(rtxspecial::kMaxRecords) + " scan records";
         } else {
             double seconds = 0.0;
-            if (rtxspecial::load(special_text(s, light_tree, scan_groups, scan_recs), scan_variant(s, light_tree), ctx->special, ctx->special_note, &seconds)) {
+            if (rtxspecial::load(special_text(s, light_tree, scan_groups, scan_recs, scan_info), scan_variant(s, light_tree), ctx->special, ctx->special_note, &seconds)) {
                 ctx->info.scan_specialized = 1;
                 ctx->info.specialize_seconds = (float)seconds;
             }

@@ -210,6 +210,20 @@ struct HitRec {
 };
 RTX_DEV uint32_t rec_mat_kind(const HitRec& r) { return (r.bits >> kInfoMatShift) & 3u; }
 
+// What the scene holds, for kernels compiled for one scene (rtx_special.cpp defines RTX_SPECIAL_FEATURES):
+// a test for something the scene does not have - a textured surface, a fuzzy metal, a sphere among the
+// lights - is then decided at compile time and the code behind it goes.  Kernels that serve any scene
+// see every feature.
+constexpr uint32_t kFeatTextured = 1u, kFeatNeedsUV = 2u, kFeatMetal = 4u, kFeatFuzz = 8u, kFeatDielectric = 16u,
+                   kFeatLambertian = 32u, kFeatEmitter = 64u, kFeatLightRect = 128u, kFeatLightSphere = 256u,
+                   kFeatLightOther = 512u;
+#ifdef RTX_SPECIAL_FEATURES
+constexpr uint32_t kSceneFeatures = RTX_SPECIAL_FEATURES;
+#else
+constexpr uint32_t kSceneFeatures = 0xffffffffu;
+#endif
+constexpr bool scene_has(uint32_t feature) { return (kSceneFeatures & feature) != 0u; }
+
 // ---------------------------------------------------------------------------
 // primitive tests.  Both return the accepted t or leave `t_out` untouched.
 // ---------------------------------------------------------------------------
@@ -470,7 +484,7 @@ RTX_DEV void finish_scan_hit(const SceneView& sc, uint32_t slot, float t, V3 o, 
     rec.param = I.param;
     rec.color = v3(I.r, I.g, I.b);
     rec.u = rec.v = 0.0f;
-    if (want_uv || (I.bits & kInfoNeedsUV)) {  // texture coordinates live in the primitive's frame
+    if (want_uv || (scene_has(kFeatNeedsUV) && (I.bits & kInfoNeedsUV))) {  // texture coordinates live in the primitive's frame
         const Prim W = sc.prims[sc.scan_orig[slot]];
         const uint32_t kind = I.bits & kInfoKindMask;
         V3 pl = p;
@@ -1079,7 +1093,7 @@ RTX_DEV V3 texture_value(const SceneView& sc, uint32_t tex, float u, float v, V3
 
 // Texture::value of the hit's material texture: plain colours come with the hit record.
 RTX_DEV V3 surface_color(const SceneView& sc, const HitRec& rec) {
-    if (rec.bits & kInfoTextured) return texture_value(sc, rec.texture, rec.u, rec.v, rec.p);
+    if (scene_has(kFeatTextured) && (rec.bits & kInfoTextured)) return texture_value(sc, rec.texture, rec.u, rec.v, rec.p);
     return rec.color;
 }
 
@@ -1164,9 +1178,9 @@ RTX_DEV V3 sample_direction(const SceneView& sc, V3 o, V3 n, RtxRng& rng) {
         E = at32(sc.lights, index);  // per-lane
         kind = E.kind;
     }
-    const bool is_sphere = kind == RTX_LIGHT_SPHERE;
-    const bool is_rect = kind == RTX_LIGHT_RECT_XZ;
-    if (!(is_sphere | is_rect | (kind == kSampleCosine))) return v3(1.0f, 0.0f, 0.0f);
+    const bool is_sphere = scene_has(kFeatLightSphere) && kind == RTX_LIGHT_SPHERE;
+    const bool is_rect = scene_has(kFeatLightRect) && kind == RTX_LIGHT_RECT_XZ;
+    if (scene_has(kFeatLightOther) && !(is_sphere | is_rect | (kind == kSampleCosine))) return v3(1.0f, 0.0f, 0.0f);
     const float r1 = rng_nextf(&rng);
     const float r2 = rng_nextf(&rng);
     if (is_rect) {
@@ -1508,7 +1522,7 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
         return pin(ps);
     }
     const uint32_t mat_kind = rec_mat_kind(rec);
-    if (mat_kind == RTX_MAT_DIFFUSE_LIGHT) {  // DiffuseLight.h:17-28: emits on the front face, never scatters
+    if (scene_has(kFeatEmitter) && mat_kind == RTX_MAT_DIFFUSE_LIGHT) {  // DiffuseLight.h:17-28: emits on the front face, never scatters
         V3 e = v3(0.0f, 0.0f, 0.0f);
         if (dot(rec.n, ps.d) < 0.0f) e = surface_color(sc, rec);
         L = vmul(ps.T, e);
@@ -1518,7 +1532,8 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
     L = v3(0.0f, 0.0f, 0.0f);
     if (ps.depth >= max_depth) return pin(ps);  // Scene.cpp:108
 
-    if (mat_kind == RTX_MAT_LAMBERTIAN) {
+    // (a scene without Metal and Dielectric: what is not an emitter is a Lambertian)
+    if (scene_has(kFeatLambertian) && (!scene_has(kFeatMetal | kFeatDielectric) || mat_kind == RTX_MAT_LAMBERTIAN)) {
         V3 albedo = surface_color(sc, rec);  // Lambertian.cpp:17
         const V3 dir = kLightTree ? sample_direction_tree(sc, rec.p, rec.n, ps.rng)
                                   : sample_direction<kListLit>(sc, rec.p, rec.n, ps.rng);
@@ -1559,14 +1574,14 @@ RTX_DEV bool shade(const SceneView& sc, uint32_t max_depth, bool hit, const HitR
     {   // Metal (Metal.cpp:9-17) and Dielectric (Dielectric.cpp:7-45) in one pass: both mirror the
         // incoming direction about the normal - Metal the normalised one, Dielectric the raw one -
         // so the few lanes of either kind share that part instead of running two separate blocks.
-        const bool metal = mat_kind == RTX_MAT_METAL;
+        const bool metal = scene_has(kFeatMetal) && (!scene_has(kFeatDielectric) || mat_kind == RTX_MAT_METAL);
         const float dn = dot(ps.d, rec.n);
         const float inv_len = finvsqrt(dot(ps.d, ps.d));
         const float s = metal ? inv_len : 1.0f;
         V3 reflected = ps.d * s - rec.n * ((2.0f * dn) * s);  // reflect, Util.h:56-58
         V3 dir = reflected;
         if (metal) {
-            if (rec.param != 0.0f) {  // a perfect mirror ignores the fuzz vector
+            if (scene_has(kFeatFuzz) && rec.param != 0.0f) {  // a perfect mirror ignores the fuzz vector
                 V3 q;
                 do {  // random_in_unit_sphere, Util.h:32-38
                     float rz = rng_nextf(&ps.rng);

@@ -182,6 +182,31 @@ std::string lights_source(const std::vector<rtxd::Light>& lights, uint32_t n_lig
     return s;
 }
 
+std::string features_source(const std::vector<rtxd::ScanHit>& hits, const std::vector<rtxd::Light>& lights, uint32_t n_lights,
+                            bool light_tree) {
+    // (the bit values are those of kFeat* in rtx_core.h)
+    uint32_t f = 0u;
+    for (const rtxd::ScanHit& H : hits) {
+        if (H.bits & rtxd::kInfoTextured) f |= 1u;
+        if (H.bits & rtxd::kInfoNeedsUV) f |= 2u;
+        switch ((H.bits >> rtxd::kInfoMatShift) & 3u) {
+            case RTX_MAT_METAL: f |= 4u | (H.param != 0.0f ? 8u : 0u); break;
+            case RTX_MAT_DIELECTRIC: f |= 16u; break;
+            case RTX_MAT_LAMBERTIAN: f |= 32u; break;
+            default: f |= 64u; break;
+        }
+    }
+    if (light_tree) {
+        f |= 128u | 256u | 512u;  // the tree kernels sample through code of their own
+    } else {
+        for (uint32_t l = 0; l < n_lights; ++l)
+            f |= lights[l].kind == RTX_LIGHT_RECT_XZ ? 128u : lights[l].kind == RTX_LIGHT_SPHERE ? 256u : 512u;
+    }
+    std::string s;
+    append(s, "#define RTX_SPECIAL_FEATURES 0x%xu\n", f);
+    return s;
+}
+
 std::string scan_source(const std::vector<rtxd::ScanGroup>& groups, const std::vector<rtxd::ScanRec>& recs) {
     std::string s = "#define RTX_SPECIAL_SCAN \\\n";
     for (const rtxd::ScanGroup& G : groups) {

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "rtx.h"
 #include "rtx_device.h"
 
 namespace rtxspecial {
@@ -45,6 +46,12 @@ std::string scan_source(const std::vector<rtxd::ScanGroup>& groups, const std::v
 // (ShapeList.cpp:19-26) then runs over literals instead of scalar-loaded records.  Empty for scenes
 // without lights or with more than kMaxRecords of them.  A kernel's text is scan_source + lights_source.
 std::string lights_source(const std::vector<rtxd::Light>& lights, uint32_t n_lights, bool is_list);
+
+// What the scene holds (textured surfaces, the material kinds of its hit records, the kinds of its
+// light entries) as the definition of RTX_SPECIAL_FEATURES: tests for what it does not hold are
+// decided when its kernels are compiled.  `hits` are the records of the scan table's positions.
+std::string features_source(const std::vector<rtxd::ScanHit>& hits, const std::vector<rtxd::Light>& lights, uint32_t n_lights,
+                            bool light_tree);
 
 // Compiles the kernels around `scan` for gfx950 and loads them on the current device.  Code objects are kept
 // per process, variant and scan text, so a scene uploaded again - or on another device - is not compiled
