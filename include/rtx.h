@@ -200,16 +200,18 @@ int rtx_device_count(void);
 /*
  * Options of a context, set before the calls they affect.  Returns RTX_ERR_INVALID_ARGUMENT for an
  * unknown option or value.
- *   RTX_OPTION_SPECIALIZE_SCAN  (default 1) 1: rtx_upload_scene compiles the linear scan of a small
+ *   RTX_OPTION_SPECIALIZE_SCAN  (default 1) 1: rtx_upload_scene compiles the fast-mode kernels of a small
  *       scene (no tree, at most 64 scan records: the reference's own scene, Scene.cpp:43-86, has
- *       14) into the fast-mode kernels with the HIP run-time compiler: the scene's records become
- *       literals of straight-line code instead of a table walked at run time.  The same tests in
- *       the same order, so the same primitive wins a ray but for candidates within rounding of each
- *       other (the compiler may contract a product with a literal differently from one with a
- *       register); frames, per-sample outputs and rtx_hit of a scene all come from the compiled
- *       scan.  An upload takes 0.2 - 0.7 s longer the first time a process sees the scene.  Where the
- *       run-time compiler is missing or fails the table-driven kernels render (rtx_scene_info and
- *       rtx_scene_note say so).  0: never.  Deterministic mode is not affected.
+ *       14) for that scene with the HIP run-time compiler: its primitives become literals of a
+ *       straight-line scan instead of a table walked at run time, so do the entries of its light
+ *       list (ShapeList.cpp:19-26), and tests for what the scene does not hold (textured surfaces,
+ *       fuzzy metals, a kind of light) are left out.  The same tests in the same order, so the same
+ *       primitive wins a ray but for candidates within rounding of each other (the compiler may
+ *       contract a product with a literal differently from one with a register); frames, per-sample
+ *       outputs and rtx_hit of a scene all come from the compiled scan.  An upload takes 0.2 - 0.7 s
+ *       longer the first time a process sees the scene.  Where the run-time compiler is missing or
+ *       fails the table-driven kernels render (rtx_scene_info and rtx_scene_note say so).  0: never.
+ *       Deterministic mode is not affected.
  */
 enum { RTX_OPTION_SPECIALIZE_SCAN = 1 };
 int rtx_set_option(RtxContext* ctx, uint32_t option, uint64_t value);
@@ -223,9 +225,10 @@ int rtx_set_option(RtxContext* ctx, uint32_t option, uint64_t value);
  */
 int rtx_prepare_scene(const RtxScene* scene);
 /*
- * The generated part of that kernel's source, for inspection: the scene's scan as the body of the
- * RTX_SPECIAL_SCAN macro (one line per transform group and per record, in the order the
- * table-driven kernel tests them, operands as the bits of the fp32 values); the rest of the
+ * The generated part of that kernel's source, for inspection: the scene's feature set
+ * (RTX_SPECIAL_FEATURES), its scan as the body of the RTX_SPECIAL_SCAN macro (one line per transform
+ * group and per record, in the order the table-driven kernel tests them, operands as the bits of
+ * the fp32 values) and, for a light list without a tree, its entries (RTX_SPECIAL_LIGHTS); the rest of the
  * translation unit is raytrace_amd/csrc/rtx_core.h as built into the library.  Copies at most
  * `capacity` bytes (NUL-terminated) into `text` and stores the size of the whole text, NUL
  * included, in *needed (either may be null).  Errors as rtx_prepare_scene.
