@@ -84,6 +84,58 @@ def test_scene_kernels_compile_without_a_gpu():
     assert e.value.code == api.RTX_ERR_INVALID_ARGUMENT
 
 
+def test_scene_features_and_lights_in_the_generated_source():
+    """What a scene's kernels are told about it: the feature set (bit values of kFeat* in csrc/rtx_core.h) and,
+    for a light list without a tree, its entries."""
+    textured, needs_uv, metal, fuzz, dielectric, lambertian, emitter, l_rect, l_sphere, l_other = (1 << k for k in range(10))
+
+    def features(name):
+        text = api.scene_kernel_source(api.HostScene(name, 16, 9))
+        return int(re.search(r"#define RTX_SPECIAL_FEATURES 0x([0-9a-f]+)u", text).group(1), 16), text
+
+    f, text = features("cornell")  # aluminium mirror, glass, white walls, lamp; lights: ceiling rect + sphere
+    assert f == metal | dielectric | lambertian | emitter | l_rect | l_sphere
+    assert text.count("RTX_SPECIAL_LIGHT(") == 2 and "RTX_SPECIAL_LIGHT_WEIGHT 0x3f000000u" in text  # 1 / 2
+    f, _ = features("cornell_classic")  # two white boxes, one ceiling lamp
+    assert f == lambertian | emitter | l_rect
+    f, _ = features("textured")
+    assert f & textured and f & needs_uv
+    f, text = features("sky_spheres")  # no light shape at all
+    assert not f & (l_rect | l_sphere | l_other | emitter) and "RTX_SPECIAL_LIGHTS" not in text
+    f, text = features("cornell_light_tree")  # nested lists: the tree kernels, no literal list
+    assert f & l_rect and f & l_sphere and f & l_other and "RTX_SPECIAL_LIGHTS" not in text
+    f, _ = features("cornell_extra")
+    assert f & fuzz and f & dielectric
+
+
+def test_scenes_compile_concurrently_from_several_threads():
+    """rtx_prepare_scene is what an application calls from worker threads: four scenes at once, then each
+    again from the cache."""
+    import threading
+    import time
+
+    names = ["cornell_classic", "cornell_extra", "sky_sphere_lit", "cornell_side_lights"]
+    scenes = [api.HostScene(n, 24, 16) for n in names]
+    errors = []
+
+    def work(scene):
+        try:
+            api.prepare_scene(scene)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(sc,)) for sc in scenes]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    t0 = time.time()
+    for sc in scenes:
+        api.prepare_scene(sc)
+    assert time.time() - t0 < 0.2
+
+
 def test_a_scan_that_does_not_compile_is_refused_with_the_compilers_message(tmp_path):
     """The failure path of the run-time compilation (tests/special_check.cpp, host only): rtx_upload_scene
     keeps the table-driven kernels when it returns false."""
