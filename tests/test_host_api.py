@@ -143,9 +143,12 @@ def test_a_scan_that_does_not_compile_is_refused_with_the_compilers_message(tmp_
 
     csrc = os.path.join(ROOT, "raytrace_amd", "csrc")
     exe = str(tmp_path / "special_check")
+    # (rtx_sources.cpp copies the device sources in by paths relative to its own directory)
+    sources = str(tmp_path / "rtx_sources.o")
+    subprocess.run(["g++", "-O1", "-c", "rtx_sources.cpp", "-o", sources], check=True, capture_output=True, cwd=csrc)
     subprocess.run(["hipcc", "-std=c++17", "-O1", "-x", "hip", "--offload-arch=gfx950", "-I" + csrc, "-I" + os.path.join(ROOT, "include"),
                     os.path.join(ROOT, "tests", "special_check.cpp"), os.path.join(csrc, "rtx_special.cpp"), "-x", "none",
-                    os.path.join(csrc, "build", "rtx_sources.o"), "-ldl", "-o", exe], check=True, capture_output=True)
+                    sources, "-ldl", "-o", exe], check=True, capture_output=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
 
