@@ -110,7 +110,7 @@ RTX_NOALLOC_MAX_PIXELS = 1 << 21
 RTXH_SYMBOLS = (
     "rtxh_last_error", "rtxh_scene_create", "rtxh_scene_view", "rtxh_scene_destroy",
     "rtxh_image_write", "rtxh_resolve", "rtxh_write_bmp", "rtxh_render_to_bmp",
-    "rtxh_render_to_bmp_multi", "rtxh_load_image",
+    "rtxh_render_to_bmp_multi", "rtxh_load_image", "rtxh_set_kernel_compilation",
 )
 
 
@@ -245,6 +245,8 @@ def load_libhost() -> C.CDLL:
                                            C.c_uint64, C.c_int, C.POINTER(C.c_ulonglong),
                                            C.POINTER(C.c_double)]
         lib.rtxh_render_to_bmp.restype = C.c_int
+        lib.rtxh_set_kernel_compilation.argtypes = [C.c_int]
+        lib.rtxh_set_kernel_compilation.restype = C.c_int
         _libhost = lib
     return _libhost
 

@@ -8,7 +8,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <array>
 #include <vector>
@@ -88,6 +91,18 @@ hipError_t scratch_pointer(int device, void** out) {
 
 }  // namespace
 
+// A compilation of a scene's kernels on a thread of its own (RTX_OPTION_SPECIALIZE_SCAN = 2).  The
+// thread only compiles into the process's cache (no device call); the context's next render call
+// loads the code object on its device.  The context and the thread share the job, so a context that
+// is destroyed or gets another scene simply drops its reference.
+struct SpecialJob {
+    std::string text;
+    rtxspecial::Variant variant;
+    std::atomic<int> state{0};  // 0 compiling, 1 in the cache, 2 failed
+    std::string why;            // (written before state becomes 2)
+    double seconds = 0.0;
+};
+
 struct RtxContext {
     int device = 0;
     bool has_scene = false;
@@ -120,9 +135,10 @@ struct RtxContext {
     DeviceArray<RtxHit> hits;
     DeviceArray<uint8_t> rgb8;
     DeviceArray<float> peer_frames;  // rtx_render_multi: the other contexts' partial frames, on context 0's GPU
-    bool specialize_scan = true;   // RTX_OPTION_SPECIALIZE_SCAN
-    rtxspecial::Kernel special;    // the trace kernel compiled for the uploaded scene's scan, if any
-    std::string special_note;      // why there is none
+    uint32_t specialize_scan = 1;  // RTX_OPTION_SPECIALIZE_SCAN: 0 never, 1 at upload, 2 in the background
+    rtxspecial::Kernel special;    // the kernels compiled for the uploaded scene, if any
+    std::string special_note;      // why there are none
+    std::shared_ptr<SpecialJob> special_job;  // a compilation in the background, not yet adopted
     uint64_t scene_hash = 0;  // of everything rtx_upload_scene was given (rtx_render_multi compares it)
     void* scratch = nullptr;  // this device's copy of the file-scope scratch array (rtx_render_noalloc)
 };
@@ -505,6 +521,23 @@ rtxspecial::Variant scan_variant(const RtxScene* s, bool light_tree) {
     return v;
 }
 
+// Takes over the kernels a background compilation has finished (called by the render entry points,
+// with the context's device current): from the process's cache onto this device.
+void adopt_special_job(RtxContext* ctx) {
+    if (!ctx->special_job) return;
+    const int state = ctx->special_job->state.load(std::memory_order_acquire);
+    if (state == 0) return;
+    const std::shared_ptr<SpecialJob> job = std::move(ctx->special_job);
+    ctx->special_job.reset();
+    if (state == 1 && rtxspecial::load(job->text, job->variant, ctx->special, ctx->special_note, nullptr)) {
+        ctx->special_note.clear();
+        ctx->info.scan_specialized = 1;
+        ctx->info.specialize_seconds = (float)job->seconds;
+    } else if (state == 2) {
+        ctx->special_note = job->why;
+    }
+}
+
 // A trace kernel compiled for the uploaded scene: the launch rtx_fast_mode::launch_trace makes for a
 // scan scene, through the module API.
 hipError_t launch_special_trace(hipFunction_t kernel, rtxd::TraceArgs a, hipStream_t stream) {
@@ -645,8 +678,8 @@ void rtx_destroy(RtxContext* ctx) {
 
 int rtx_set_option(RtxContext* ctx, uint32_t option, uint64_t value) {
     if (!ctx) return fail(RTX_ERR_INVALID_ARGUMENT, "context is null");
-    if (option == RTX_OPTION_SPECIALIZE_SCAN && value <= 1) {
-        ctx->specialize_scan = value != 0;
+    if (option == RTX_OPTION_SPECIALIZE_SCAN && value <= 2) {
+        ctx->specialize_scan = (uint32_t)value;
         return RTX_OK;
     }
     return fail(RTX_ERR_INVALID_ARGUMENT, "unknown option or value");
@@ -883,6 +916,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     // the scan of a small scene compiled into the fast-mode trace kernel (the variant launch_trace would pick
     // for this scene's frames)
     rtxspecial::unload(ctx->special);
+    ctx->special_job.reset();
     ctx->special_note.clear();
     ctx->info.scan_specialized = 0;
     ctx->info.specialize_seconds = 0.0f;
@@ -891,6 +925,18 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     if (candidate && ctx->specialize_scan) {
         if (scan_recs.size() - 1 > rtxspecial::kMaxRecords) {
             ctx->special_note = "more than " + std::to_string(rtxspecial::kMaxRecords) + " scan records";
+        } else if (ctx->specialize_scan == 2u) {
+            auto job = std::make_shared<SpecialJob>();
+            job->text = special_text(s, light_tree, scan_groups, scan_recs, scan_info);
+            job->variant = scan_variant(s, light_tree);
+            ctx->special_job = job;
+            ctx->special_note = "compiling in the background";
+            std::thread([job] {
+                std::string why;
+                const bool ok = rtxspecial::prepare(job->text, job->variant, why, &job->seconds);
+                job->why = why;
+                job->state.store(ok ? 1 : 2, std::memory_order_release);
+            }).detach();
         } else {
             double seconds = 0.0;
             if (rtxspecial::load(special_text(s, light_tree, scan_groups, scan_recs, scan_info), scan_variant(s, light_tree), ctx->special, ctx->special_note, &seconds)) {
@@ -909,16 +955,22 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
 int rtx_scene_info(RtxContext* ctx, RtxSceneInfo* out) {
     if (!ctx || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "null argument");
     if (!ctx->has_scene) return fail(RTX_ERR_NO_SCENE, "no scene uploaded");
+    if (ctx->special_job) {  // (a finished background compilation is taken over here too)
+        RTX_HIP(hipSetDevice(ctx->device));
+        adopt_special_job(ctx);
+    }
     *out = ctx->info;
     return RTX_OK;
 }
 
-int rtx_render_device(RtxContext* ctx, const RtxParams* params, float* d_accum_rgb,
-                      unsigned long long* d_rays, void* hip_stream) {
+// rtx_render_device; `may_load` = 0 for the caller that must not allocate (loading a code object does)
+static int render_device(RtxContext* ctx, const RtxParams* params, float* d_accum_rgb, unsigned long long* d_rays,
+                         void* hip_stream, bool may_load) {
     int rc = check_params(ctx, params);
     if (rc != RTX_OK) return rc;
     if (!d_accum_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "accumulator is null");
     RTX_HIP(hipSetDevice(ctx->device));
+    if (may_load) adopt_special_job(ctx);
     rtxd::TraceArgs a = make_trace_args(ctx, params);
     a.accum = d_accum_rgb;
     a.rays = d_rays;
@@ -931,6 +983,11 @@ int rtx_render_device(RtxContext* ctx, const RtxParams* params, float* d_accum_r
         RTX_HIP(rtx_fast_mode::launch_trace(a, stream));
     }
     return RTX_OK;
+}
+
+int rtx_render_device(RtxContext* ctx, const RtxParams* params, float* d_accum_rgb,
+                      unsigned long long* d_rays, void* hip_stream) {
+    return render_device(ctx, params, d_accum_rgb, d_rays, hip_stream, true);
 }
 
 int rtx_render(RtxContext* ctx, const RtxParams* params, float* accum_rgb, uint64_t* rays_out) {
@@ -974,7 +1031,7 @@ int rtx_render_noalloc(RtxContext* ctx, const RtxParams* params, float* accum_rg
     // is either overwritten by the kernel (accumulate == 0) or replaced by the caller's
     RTX_HIP(hipMemsetAsync(d_rays, 0, sizeof(unsigned long long), nullptr));
     if (params->accumulate) RTX_HIP(hipMemcpy(d_accum, accum_rgb, bytes, hipMemcpyHostToDevice));
-    rc = rtx_render_device(ctx, params, d_accum, d_rays, nullptr);
+    rc = render_device(ctx, params, d_accum, d_rays, nullptr, false);
     if (rc != RTX_OK) return rc;
     RTX_HIP(hipStreamSynchronize(nullptr));
     RTX_HIP(hipMemcpy(accum_rgb, d_accum, bytes, hipMemcpyDeviceToHost));
@@ -1094,6 +1151,7 @@ int rtx_render_samples(RtxContext* ctx, const RtxParams* params, float* sample_r
     if (n_samples > (1ull << 28)) return fail(RTX_ERR_TOO_LARGE, "per-sample output limited to 2^28 samples");
     if (n_samples == 0) return RTX_OK;
     RTX_HIP(hipSetDevice(ctx->device));
+    adopt_special_job(ctx);
     RTX_HIP(ctx->sample_rgb.resize(n_samples * 3));
     RTX_HIP(ctx->sample_segments.resize(n_samples));
     rtxd::TraceArgs a = make_trace_args(ctx, params);
@@ -1119,6 +1177,7 @@ int rtx_hit(RtxContext* ctx, uint32_t n, const float* origins, const float* dire
     if (!origins || !directions || !hits) return fail(RTX_ERR_INVALID_ARGUMENT, "null ray / hit array");
     if (n > (1u << 28)) return fail(RTX_ERR_TOO_LARGE, "more than 2^28 rays");
     RTX_HIP(hipSetDevice(ctx->device));
+    adopt_special_job(ctx);
     RTX_HIP(ctx->ray_o.resize((size_t)n * 3));
     RTX_HIP(ctx->ray_d.resize((size_t)n * 3));
     RTX_HIP(ctx->hits.resize(n));

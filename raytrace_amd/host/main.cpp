@@ -9,6 +9,7 @@
 
 extern "C" int rtxh_render_to_bmp(const char* name, const char* path, int w, int h, int spp, int deterministic,
                                   unsigned long long seed, int device, unsigned long long* rays, double* seconds);
+extern "C" int rtxh_set_kernel_compilation(int mode);
 extern "C" int rtxh_render_to_bmp_multi(const char* name, const char* path, int w, int h, int spp, int deterministic,
                                         unsigned long long seed, const int* devices, int n_devices,
                                         unsigned long long* rays, double* seconds);
@@ -43,10 +44,16 @@ int main(int argc, char** argv) {
             }
         }
         else if (a == "--deterministic") det = 1;
+        else if (a == "--compile") {
+            const std::string m = next("--compile");
+            const int mode = m == "auto" ? -1 : m == "never" ? 0 : m == "upload" ? 1 : m == "background" ? 2 : 3;
+            if (!rtxh_set_kernel_compilation(mode)) { std::fprintf(stderr, "bad --compile '%s' (auto, never, upload, background)\n", m.c_str()); return 2; }
+        }
         else {
             std::fprintf(stderr,
                          "usage: %s [--scene NAME] [--out FILE.bmp] [--width W] [--height H] [--spp N]\n"
-                         "          [--seed S] [--device D | --devices D0,D1,...] [--deterministic]\n", argv[0]);
+                         "          [--seed S] [--device D | --devices D0,D1,...] [--deterministic]\n"
+                         "          [--compile auto|never|upload|background]   (kernels compiled for the scene)\n", argv[0]);
             return 2;
         }
     }

@@ -676,11 +676,16 @@ bool Scene::render() {
     }
     const int nx = m_image->width(), ny = m_image->height();
     const std::vector<int> devices = m_devices.empty() ? std::vector<int>{m_device} : m_devices;
+    KernelCompilation compile = m_kernelCompilation;
+    if (compile == KernelCompilation::Auto)
+        compile = (unsigned long long)nx * (unsigned long long)ny * (unsigned long long)m_samples >= kCompileFromSamples
+                      ? KernelCompilation::AtUpload : KernelCompilation::Never;
     std::vector<RtxContext*> ctxs;
     bool ok = true;
     for (int d : devices) {
         RtxContext* ctx = nullptr;
         ok = rtx_create(d, &ctx) == RTX_OK && (ctxs.push_back(ctx), true) &&
+             rtx_set_option(ctx, RTX_OPTION_SPECIALIZE_SCAN, (uint64_t)compile) == RTX_OK &&
              rtx_upload_scene(ctx, flat.view(), RTX_ACCEL_AUTO) == RTX_OK;
         if (!ok) break;
     }

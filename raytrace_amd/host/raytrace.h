@@ -483,6 +483,15 @@ public:
     // (the default) means the single device of setDevice().
     void setDevices(const std::vector<int>& d) { m_devices = d; }
     void setSamplesPerLaunch(int s) { m_samplesPerLaunch = s; }
+    // Whether the GPU library compiles its fast-mode kernels for this scene (RTX_OPTION_SPECIALIZE_SCAN
+    // of include/rtx.h; scenes of at most 64 primitives): Never, AtUpload (render() then takes 0.3 - 0.7 s
+    // longer to start and its launches run 7 - 22 % faster), InBackground (render() starts at once and
+    // switches kernels when they are ready: two runs may then differ in the rounding of some samples), or
+    // Auto, the default: AtUpload for a frame of at least kCompileFromSamples pixel samples - where the
+    // compilation is paid back by the launches - and Never below.
+    enum class KernelCompilation { Auto = -1, Never = 0, AtUpload = 1, InBackground = 2 };
+    static constexpr unsigned long long kCompileFromSamples = 120000000000ull;  // 1080p x 58 000 spp: about 3 s of launches
+    void setKernelCompilation(KernelCompilation m) { m_kernelCompilation = m; }
 
     // Flatten camera / world / light into `out`.  False on a scene the GPU path
     // cannot express (see FlatScene::error()).
@@ -507,7 +516,11 @@ protected:
     bool m_deterministic = false;
     int m_device = 0;
     std::vector<int> m_devices;
-    int m_samplesPerLaunch = 512;  // per device; each rtx_render call also moves the frame over PCIe twice
+    // per device.  Each rtx_render call also moves the frame over PCIe (once, twice when it adds to earlier calls) and
+    // ends on its slowest waves: 1080p x 4 096 spp through calls of 512 / 1 024 / 4 096 samples runs at 112 / 122 /
+    // 125 Grays/s end to end
+    int m_samplesPerLaunch = 4096;
+    KernelCompilation m_kernelCompilation = KernelCompilation::Auto;
     std::string m_error;
     unsigned long long m_rays = 0;
     double m_seconds = 0.0;

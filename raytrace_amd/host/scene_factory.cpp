@@ -118,6 +118,17 @@ int rtxh_load_image(const char* path, int* w, int* h, uint8_t* out, size_t capac
     return 1;
 }
 
+// Scene::setKernelCompilation for the renders below (-1 auto, 0 never, 1 at upload, 2 in the background).
+static int g_kernel_compilation = -1;
+int rtxh_set_kernel_compilation(int mode) {
+    if (mode < -1 || mode > 2) {
+        g_error = "kernel compilation mode must be -1 (auto), 0 (never), 1 (at upload) or 2 (in the background)";
+        return 0;
+    }
+    g_kernel_compilation = mode;
+    return 1;
+}
+
 // The whole Scene::render() path: build, flatten, GPU render, filters, BMP.
 int rtxh_render_to_bmp(const char* name, const char* path, int w, int h, int spp, int deterministic,
                        uint64_t seed, int device, unsigned long long* rays, double* seconds) {
@@ -125,6 +136,7 @@ int rtxh_render_to_bmp(const char* name, const char* path, int w, int h, int spp
     scene.setDeterministic(deterministic != 0);
     scene.setSeed(seed);
     scene.setDevice(device);
+    scene.setKernelCompilation(static_cast<Scene::KernelCompilation>(g_kernel_compilation));
     if (!scene.render()) {
         g_error = scene.built() ? scene.lastError() : std::string("unknown scene '") + name + "'";
         return 0;
@@ -146,6 +158,7 @@ int rtxh_render_to_bmp_multi(const char* name, const char* path, int w, int h, i
     scene.setDeterministic(deterministic != 0);
     scene.setSeed(seed);
     scene.setDevices(std::vector<int>(devices, devices + n_devices));
+    scene.setKernelCompilation(static_cast<Scene::KernelCompilation>(g_kernel_compilation));
     if (!scene.render()) {
         g_error = scene.built() ? scene.lastError() : std::string("unknown scene '") + name + "'";
         return 0;

@@ -77,3 +77,36 @@ def test_scene_render_over_two_contexts_writes_the_same_file(gpu_ctx, tmp_path):
     f = np.frombuffer(open(fast, "rb").read(), np.uint8)[54:].astype(float).mean()
     r = np.frombuffer(open(det, "rb").read(), np.uint8)[54:].astype(float).mean()
     assert abs(f / r - 1) < 0.03
+
+
+def test_scene_render_with_the_kernels_compiled_for_the_scene(gpu_ctx, tmp_path):
+    """Scene::setKernelCompilation / `rtx_render --compile`: the same fast-mode image, up to the noise of a few
+    samples whose paths differ in rounding, from the table-driven kernels and from the compiled ones; the
+    deterministic mode is untouched by the setting."""
+    lib = api.load_libhost()
+    name, w, h, spp = "cornell_builtin", 64, 36, 64
+    rays, seconds = C.c_ulonglong(0), C.c_double(0.0)
+    files, counts = {}, {}
+    try:
+        for label, mode in (("never", 0), ("upload", 1), ("background", 2), ("auto", -1)):
+            assert lib.rtxh_set_kernel_compilation(mode)
+            files[label] = str(tmp_path / f"{label}.bmp")
+            assert lib.rtxh_render_to_bmp(name.encode(), files[label].encode(), w, h, spp, 0, 4, 0, C.byref(rays), C.byref(seconds)), \
+                lib.rtxh_last_error().decode()
+            counts[label] = rays.value
+        det = {}
+        for label, mode in (("never", 0), ("upload", 1)):
+            assert lib.rtxh_set_kernel_compilation(mode)
+            det[label] = str(tmp_path / f"det_{label}.bmp")
+            assert lib.rtxh_render_to_bmp(name.encode(), det[label].encode(), w, h, 8, 1, 4, 0, C.byref(rays), C.byref(seconds))
+        assert not lib.rtxh_set_kernel_compilation(5)
+    finally:
+        lib.rtxh_set_kernel_compilation(-1)
+    image = {k: np.frombuffer(open(v, "rb").read(), np.uint8)[54:].astype(int) for k, v in files.items()}
+    # a small frame is below the size from which "auto" compiles: the table-driven kernels, bit for bit
+    assert np.array_equal(image["auto"], image["never"]) and counts["auto"] == counts["never"]
+    for label in ("upload", "background"):
+        d = np.abs(image[label] - image["never"])
+        assert (d > 0).mean() < 0.05 and abs(image[label].mean() / image["never"].mean() - 1) < 5e-3, label
+        assert abs(counts[label] / counts["never"] - 1) < 2e-3
+    assert open(det["never"], "rb").read() == open(det["upload"], "rb").read()

@@ -251,7 +251,7 @@ def test_fast_scan_frame_is_the_sum_of_its_samples(gpu_ctx, name, specialize):
     assert np.allclose(frame, rgb.reshape(h, w, spp, 3).sum(axis=2)[::-1], rtol=1e-4, atol=1e-5)
 
 
-def _tilted_cornell(w, h):
+def _tilted_cornell(w, h, degrees=20.0):
     """The reference's Cornell box with its two boxes turned about a tilted axis instead of the y axis
     (a transform whose composed map has no zero entry).  Returns the scene and what keeps its arrays alive."""
     import ctypes as C
@@ -264,7 +264,7 @@ def _tilted_cornell(w, h):
     turned = 0
     for i in range(n):
         if v.step_kind[i] == api.RTX_STEP_ROTATE:
-            half = np.radians(20.0 if turned == 0 else -12.0) / 2
+            half = np.radians(degrees if turned == 0 else -12.0) / 2
             q = np.concatenate([axis * np.sin(half), [np.cos(half)]]).astype(np.float32)
             cols["step_x"][i], cols["step_y"][i], cols["step_z"][i], cols["step_w"][i] = (float(c) for c in q)
             turned += 1
@@ -352,6 +352,47 @@ def test_scan_compiled_for_the_scene_agrees_with_the_table_scan(gpu_ctx, name, l
     del keep
 
 
+def test_background_compilation_does_not_hold_up_the_upload_and_takes_over_when_ready(gpu_ctx):
+    """RTX_OPTION_SPECIALIZE_SCAN = 2: the upload returns without waiting for the compiler, frames come from
+    the table-driven kernels until the compiled ones are in the process's cache, and the next call takes
+    them over; both kernels render the same estimator (same paths but for rounding)."""
+    import time
+
+    w, h, spp = 96, 54, 16
+    scene, keep = _tilted_cornell(w, h, degrees=33.0)  # (a scene no other test has compiled in this process)
+    p = gpu_ctx.params(w, h, 0, spp, mode=api.RTX_MODE_FAST, seed=3)
+    try:
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 2)
+        t = time.time()
+        gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+        upload_seconds = time.time() - t
+        note = gpu_ctx.note()
+        first, first_rays = gpu_ctx.render(p)  # (may already be the compiled kernels on a fast machine)
+        deadline = time.time() + 20.0
+        while gpu_ctx.info().scan_specialized == 0 and time.time() < deadline:
+            time.sleep(0.02)
+        info = gpu_ctx.info()
+        assert info.scan_specialized == 1 and gpu_ctx.note() == "", gpu_ctx.note()
+        assert info.specialize_seconds > 0.05
+        assert upload_seconds < info.specialize_seconds + 0.15, (upload_seconds, info.specialize_seconds)
+        assert note in ("compiling in the background", "")
+        second, second_rays = gpu_ctx.render(p)
+        # another context takes the code object from the cache at once, whatever its option says
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 1)
+        gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+        assert gpu_ctx.info().scan_specialized == 1 and gpu_ctx.info().specialize_seconds == 0.0
+        third, third_rays = gpu_ctx.render(p)
+    finally:
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 1)
+    assert np.array_equal(second, third) and second_rays == third_rays
+    assert abs(first_rays / second_rays - 1) < 2e-3
+    differ = (first != second).any(axis=2).mean()
+    assert differ < 0.2 and abs(float(first.sum()) / float(second.sum()) - 1) < 2e-2, differ
+    with pytest.raises(api.RtxError):
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 3)
+    del keep
+
+
 def test_scan_is_specialized_only_for_scans_of_at_most_64_records(gpu_ctx):
     """Scenes rendered through the tree keep their kernels silently; a scan that is too long for
     straight-line code keeps the table-driven kernels with a note."""
@@ -363,7 +404,7 @@ def test_scan_is_specialized_only_for_scans_of_at_most_64_records(gpu_ctx):
     with pytest.raises(api.RtxError):
         gpu_ctx.set_option(99, 1)
     with pytest.raises(api.RtxError):
-        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 2)
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 7)
 
 
 def test_fast_mode_converges_to_cpu_ground_truth(gpu_ctx):
