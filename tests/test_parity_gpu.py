@@ -464,8 +464,19 @@ def test_fast_mode_against_the_references_own_ground_truth(gpu_ctx, name, w, h, 
     mean = g["mean"].astype(np.float32)
     gt = np.clip(mean, 0, 1)
     scene = api.HostScene(name, w, h)
-    for accel in accels:
-        gpu_ctx.upload(scene, accel)
+    # (scans of at most 64 records: once with the kernels compiled for the scene - the default - and once
+    # with the table-driven ones, which render where that compilation is switched off, fails or is still
+    # running in the background)
+    cases = [(accel, 1) for accel in accels]
+    cases += [(accel, 0) for accel in accels if accel == api.RTX_ACCEL_LINEAR]
+    for accel, compiled in cases:
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, compiled)
+        try:
+            gpu_ctx.upload(scene, accel)
+        finally:
+            gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 1)
+        if accel == api.RTX_ACCEL_LINEAR:
+            assert gpu_ctx.info().scan_specialized == compiled
         for n, seeds in ((64, 16), (512, 6)):
             want = g[f"ref_mse_{n}"]
             got = np.array([float(np.mean((np.clip(gpu_ctx.render(gpu_ctx.params(w, h, 0, n, seed=500 + s))[0] / n, 0, 1) - gt) ** 2))
@@ -492,7 +503,11 @@ def test_fast_mode_against_the_references_own_ground_truth(gpu_ctx, name, w, h, 
         assert abs(rays / (w * h * chunk * n_chunks) / float(g["rays_per_sample"]) - 1) < 3e-3
         # path lengths
         ws, hs, ns = [int(v) for v in g["segments_hist_frame"]]
-        gpu_ctx.upload(api.HostScene(name, ws, hs), accel)
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, compiled)
+        try:
+            gpu_ctx.upload(api.HostScene(name, ws, hs), accel)
+        finally:
+            gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 1)
         ref_hist = g["segments_hist"].astype(np.float64)
         _, seg = gpu_ctx.render_samples(gpu_ctx.params(ws, hs, 0, ns, mode=api.RTX_MODE_DETERMINISTIC, seed=77))
         assert np.array_equal(np.bincount(seg.ravel(), minlength=52)[:52], g["segments_hist"])  # the reference's stream
