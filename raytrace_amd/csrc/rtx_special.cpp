@@ -54,8 +54,10 @@ struct Rtc {
     std::string why;
 };
 
+// (this and the cache below are never destroyed: a compilation on a detached thread may still use them
+// while the process's static objects are torn down)
 const Rtc& rtc() {
-    static Rtc r;
+    static Rtc& r = *new Rtc;
     static std::once_flag once;
     std::call_once(once, [] {
         void* h = nullptr;
@@ -96,8 +98,8 @@ struct CodeObject {
     std::vector<char> image;
     std::string kernel[kKernels];  // lowered names
 };
-std::mutex g_cache_mutex;
-std::map<std::string, std::shared_ptr<CodeObject>> g_cache;  // by variant and scan text
+std::mutex& g_cache_mutex = *new std::mutex;
+std::map<std::string, std::shared_ptr<CodeObject>>& g_cache = *new std::map<std::string, std::shared_ptr<CodeObject>>;  // by variant and scan text
 
 bool compile(const std::string& scan, Variant variant, CodeObject& out, std::string& why) {
     const Rtc& r = rtc();
