@@ -215,7 +215,9 @@ int rtx_device_count(void);
  *       returns at once; the table-driven kernels render until the compiled ones are ready, and
  *       the first render call (or rtx_scene_info) after that takes them over, which loads a code
  *       object on the device (rtx_render_noalloc never does: it goes on with what the context
- *       has).  Samples rendered before and after the switch come from two compilations of the same
+ *       has; rtx_destroy and a new upload wait for a compilation that is still running, and so does
+ *       the end of the process for contexts never destroyed).  Samples rendered before and after the
+ *       switch come from two compilations of the same
  *       estimator and differ in rounding only; which call switches depends on timing, so choose 0
  *       or 1 where two runs must give the same bits.  When does it pay: the compilation costs about
  *       as much as 3 s of rendering gain back (x 1.07 - 1.22, more with dozens of lights).

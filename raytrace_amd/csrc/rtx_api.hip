@@ -91,18 +91,6 @@ hipError_t scratch_pointer(int device, void** out) {
 
 }  // namespace
 
-// A compilation of a scene's kernels on a thread of its own (RTX_OPTION_SPECIALIZE_SCAN = 2).  The
-// thread only compiles into the process's cache (no device call); the context's next render call
-// loads the code object on its device.  The context and the thread share the job, so a context that
-// is destroyed or gets another scene simply drops its reference.
-struct SpecialJob {
-    std::string text;
-    rtxspecial::Variant variant;
-    std::atomic<int> state{0};  // 0 compiling, 1 in the cache, 2 failed
-    std::string why;            // (written before state becomes 2)
-    double seconds = 0.0;
-};
-
 struct RtxContext {
     int device = 0;
     bool has_scene = false;
@@ -138,7 +126,7 @@ struct RtxContext {
     uint32_t specialize_scan = 1;  // RTX_OPTION_SPECIALIZE_SCAN: 0 never, 1 at upload, 2 in the background
     rtxspecial::Kernel special;    // the kernels compiled for the uploaded scene, if any
     std::string special_note;      // why there are none
-    std::shared_ptr<SpecialJob> special_job;  // a compilation in the background, not yet adopted
+    std::shared_ptr<rtxspecial::Job> special_job;  // a compilation in the background, not yet adopted
     uint64_t scene_hash = 0;  // of everything rtx_upload_scene was given (rtx_render_multi compares it)
     void* scratch = nullptr;  // this device's copy of the file-scope scratch array (rtx_render_noalloc)
 };
@@ -527,8 +515,9 @@ void adopt_special_job(RtxContext* ctx) {
     if (!ctx->special_job) return;
     const int state = ctx->special_job->state.load(std::memory_order_acquire);
     if (state == 0) return;
-    const std::shared_ptr<SpecialJob> job = std::move(ctx->special_job);
+    const std::shared_ptr<rtxspecial::Job> job = std::move(ctx->special_job);
     ctx->special_job.reset();
+    rtxspecial::finish(job);  // (the thread has set its state: this returns at once)
     if (state == 1 && rtxspecial::load(job->text, job->variant, ctx->special, ctx->special_note, nullptr)) {
         ctx->special_note.clear();
         ctx->info.scan_specialized = 1;
@@ -672,6 +661,7 @@ int rtx_create(int device, RtxContext** out_ctx) {
 void rtx_destroy(RtxContext* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    rtxspecial::finish(ctx->special_job);  // (waits for a compilation still running)
     rtxspecial::unload(ctx->special);
     delete ctx;
 }
@@ -916,6 +906,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     // the scan of a small scene compiled into the fast-mode trace kernel (the variant launch_trace would pick
     // for this scene's frames)
     rtxspecial::unload(ctx->special);
+    rtxspecial::finish(ctx->special_job);  // (waits for a compilation still running for the scene replaced)
     ctx->special_job.reset();
     ctx->special_note.clear();
     ctx->info.scan_specialized = 0;
@@ -926,17 +917,8 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
         if (scan_recs.size() - 1 > rtxspecial::kMaxRecords) {
             ctx->special_note = "more than " + std::to_string(rtxspecial::kMaxRecords) + " scan records";
         } else if (ctx->specialize_scan == 2u) {
-            auto job = std::make_shared<SpecialJob>();
-            job->text = special_text(s, light_tree, scan_groups, scan_recs, scan_info);
-            job->variant = scan_variant(s, light_tree);
-            ctx->special_job = job;
+            ctx->special_job = rtxspecial::start(special_text(s, light_tree, scan_groups, scan_recs, scan_info), scan_variant(s, light_tree));
             ctx->special_note = "compiling in the background";
-            std::thread([job] {
-                std::string why;
-                const bool ok = rtxspecial::prepare(job->text, job->variant, why, &job->seconds);
-                job->why = why;
-                job->state.store(ok ? 1 : 2, std::memory_order_release);
-            }).detach();
         } else {
             double seconds = 0.0;
             if (rtxspecial::load(special_text(s, light_tree, scan_groups, scan_recs, scan_info), scan_variant(s, light_tree), ctx->special, ctx->special_note, &seconds)) {

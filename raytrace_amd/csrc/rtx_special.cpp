@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -302,6 +303,57 @@ bool load(const std::string& scan, Variant variant, Kernel& out, std::string& wh
     out.samples = fn[1];
     out.hit = fn[2];
     return true;
+}
+
+namespace {
+std::mutex& g_jobs_mutex = *new std::mutex;
+std::vector<std::shared_ptr<Job>>& g_jobs = *new std::vector<std::shared_ptr<Job>>;  // started, not yet joined
+
+void join_all_jobs() {
+    std::vector<std::shared_ptr<Job>> jobs;
+    {
+        std::lock_guard<std::mutex> lock(g_jobs_mutex);
+        jobs.swap(g_jobs);
+    }
+    for (const std::shared_ptr<Job>& job : jobs)
+        if (job->thread.joinable()) job->thread.join();
+}
+}  // namespace
+
+std::shared_ptr<Job> start(const std::string& text, Variant variant) {
+    auto job = std::make_shared<Job>();
+    job->text = text;
+    job->variant = variant;
+    // The compiler library is loaded before the exit handler is registered: handlers run in reverse
+    // order, so the threads are joined before that library's own objects go.
+    (void)rtc();
+    static std::once_flag registered;
+    std::call_once(registered, [] { std::atexit(join_all_jobs); });
+    {
+        std::lock_guard<std::mutex> lock(g_jobs_mutex);
+        g_jobs.push_back(job);
+    }
+    Job* raw = job.get();  // (kept alive by g_jobs until the thread has been joined)
+    job->thread = std::thread([raw] {
+        std::string why;
+        const bool ok = prepare(raw->text, raw->variant, why, &raw->seconds);
+        raw->why = why;
+        raw->state.store(ok ? 1 : 2, std::memory_order_release);
+    });
+    return job;
+}
+
+void finish(const std::shared_ptr<Job>& job) {
+    if (!job) return;
+    {
+        std::lock_guard<std::mutex> lock(g_jobs_mutex);
+        for (size_t k = 0; k < g_jobs.size(); ++k)
+            if (g_jobs[k] == job) {
+                g_jobs.erase(g_jobs.begin() + (long)k);
+                break;
+            }
+    }
+    if (job->thread.joinable()) job->thread.join();
 }
 
 void unload(Kernel& k) {

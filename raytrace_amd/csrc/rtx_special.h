@@ -10,7 +10,10 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rtx.h"
@@ -64,5 +67,22 @@ bool load(const std::string& text, Variant variant, Kernel& out, std::string& wh
 bool prepare(const std::string& text, Variant variant, std::string& why, double* compile_seconds);
 
 void unload(Kernel& k);
+
+// A compilation on a thread of its own (RTX_OPTION_SPECIALIZE_SCAN = 2).  The thread only compiles
+// into the process's cache (no device call); the owner polls `state` and, once it is not 0, loads
+// the code object with load().  The thread is joined by finish() - which the owner calls before it
+// drops the job, so a context that is destroyed or gets another scene waits for its compilation -
+// and, for jobs whose owner never did, when the process exits: a compiler thread still running
+// while the process's libraries are torn down corrupts the heap.
+struct Job {
+    std::string text;
+    Variant variant;
+    std::atomic<int> state{0};  // 0 compiling, 1 in the cache, 2 failed
+    std::string why;            // (written before state becomes 2)
+    double seconds = 0.0;
+    std::thread thread;
+};
+std::shared_ptr<Job> start(const std::string& text, Variant variant);
+void finish(const std::shared_ptr<Job>& job);
 
 }  // namespace rtxspecial

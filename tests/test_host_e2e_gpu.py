@@ -110,3 +110,29 @@ def test_scene_render_with_the_kernels_compiled_for_the_scene(gpu_ctx, tmp_path)
         assert (d > 0).mean() < 0.05 and abs(image[label].mean() / image["never"].mean() - 1) < 5e-3, label
         assert abs(counts[label] / counts["never"] - 1) < 2e-3
     assert open(det["never"], "rb").read() == open(det["upload"], "rb").read()
+
+
+def test_a_process_may_exit_while_its_kernels_still_compile(gpu_ctx, tmp_path):
+    """Background compilation (`rtx_render --compile background`, RTX_OPTION_SPECIALIZE_SCAN = 2) of a frame that
+    is finished long before the compiler: the context waits for its compilation when it is destroyed, and a
+    context that is never destroyed is waited for when the process exits - a compiler thread still running while
+    the process's libraries are torn down ends in heap corruption (exit status 134)."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "raytrace_amd", "rtx_render")
+    if not os.path.exists(tool):
+        pytest.skip("raytrace_amd/rtx_render not built")
+    out = subprocess.run([tool, "--scene", "cornell_classic", "--width", "48", "--height", "27", "--spp", "2", "--out",
+                          str(tmp_path / "tiny.bmp"), "--compile", "background"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-400:]
+    leak = ("import sys; sys.path.insert(0, %r)\n"
+            "from raytrace_amd import api\n"
+            "ctx = api.Context(0)\n"
+            "ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 2)\n"
+            "ctx.upload(api.HostScene('small', 48, 27), api.RTX_ACCEL_LINEAR)\n"
+            "print(ctx.note(), flush=True)\n"
+            "ctx._ctx = None\n" % root)  # (no rtx_destroy)
+    out = subprocess.run([sys.executable, "-c", leak], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-400:]
+    assert "compiling in the background" in out.stdout or out.stdout.strip() == ""
