@@ -1,4 +1,5 @@
-// rtx_special.cpp — scene-specialised scan kernels: source generation, run-time compilation, cache.
+// rtx_special.cpp — kernels compiled for one scene: source generation (scan, light list, feature set),
+// run-time compilation, the process's cache of code objects, compilations on a thread of their own.
 #include "rtx_special.h"
 
 #include <dlfcn.h>
@@ -55,8 +56,8 @@ struct Rtc {
     std::string why;
 };
 
-// (this and the cache below are never destroyed: a compilation on a detached thread may still use them
-// while the process's static objects are torn down)
+// (this and the cache below are never destroyed: they must outlive every compiler thread, whatever the
+// order in which the process's static objects go)
 const Rtc& rtc() {
     static Rtc& r = *new Rtc;
     static std::once_flag once;

@@ -1,4 +1,4 @@
-// rtx_special.h — scene-specialised scan kernels, compiled at scene upload (host side).
+// rtx_special.h — kernels compiled for one scene at scene upload (host side).
 //
 // The fast-mode linear scan walks a table of records with wave-uniform scalar loads; every record
 // field is then a scalar-register operand, which halves the issue rate of the vector instruction
