@@ -144,10 +144,9 @@ def main(argv):
         ground_truth()
     if want("scatter"):
         scatter_vectors(np.random.default_rng(2031))
-    if want("gt_ref"):
-        for spec in GT_REF:
-            if want("gt_ref") or want("gt_ref", spec[0]):
-                ground_truth_ref(*spec)
+    for spec in GT_REF:  # ("gt_ref": all of them; "gt_ref:<scene>": that one)
+        if want("gt_ref", spec[0]):
+            ground_truth_ref(*spec)
     if want("resolve") or want("resolve_exhaustive"):
         resolve_thresholds(exhaustive=want("resolve_exhaustive"))
     if want("jpeg"):
@@ -353,6 +352,12 @@ GT_REF = [
     ("cornell", 480, 270, 16384, 1024),
     ("cornell_extra", 240, 135, 4096, 1024),
     ("random_field", 240, 135, 4096, 512),
+    # scan scenes whose fast-mode kernels differ in what is compiled into them: sphere lights and spheres only,
+    # Lambertian boxes with one lamp, textures with texture coordinates, a light list of 46 entries
+    ("small", 240, 135, 4096, 1024),
+    ("cornell_classic", 240, 135, 4096, 1024),
+    ("textured", 240, 135, 4096, 1024),
+    ("cornell_many_lights", 240, 135, 2048, 512),
 ]
 
 

@@ -451,6 +451,11 @@ def test_fast_mode_converges_to_cpu_ground_truth(gpu_ctx):
     ("cornell", 480, 270, (api.RTX_ACCEL_LINEAR,)),
     ("cornell_extra", 240, 135, (api.RTX_ACCEL_LINEAR, api.RTX_ACCEL_BVH)),
     ("random_field", 240, 135, (api.RTX_ACCEL_BVH,)),
+    # scan scenes whose compiled kernels differ in what is left out of them and in their light tables
+    ("small", 240, 135, (api.RTX_ACCEL_LINEAR,)),
+    ("cornell_classic", 240, 135, (api.RTX_ACCEL_LINEAR,)),
+    ("textured", 240, 135, (api.RTX_ACCEL_LINEAR,)),
+    ("cornell_many_lights", 240, 135, (api.RTX_ACCEL_LINEAR,)),
 ])
 def test_fast_mode_against_the_references_own_ground_truth(gpu_ctx, name, w, h, accels):
     """The default (fast) mode against images of the REFERENCE tracer (oracle/_ref, fixtures made by
