@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -102,6 +103,10 @@ struct CodeObject {
 };
 std::mutex& g_cache_mutex = *new std::mutex;
 std::map<std::string, std::shared_ptr<CodeObject>>& g_cache = *new std::map<std::string, std::shared_ptr<CodeObject>>;  // by variant and scan text
+// (a process that sees ever new scenes keeps the kMaxCached most recently compiled ones: a code object
+// is about 100 KB, a loaded module keeps its own copy)
+constexpr size_t kMaxCached = 256;
+std::deque<std::string>& g_cache_order = *new std::deque<std::string>;
 
 bool compile(const std::string& scan, Variant variant, CodeObject& out, std::string& why) {
     const Rtc& r = rtc();
@@ -269,7 +274,15 @@ std::shared_ptr<CodeObject> cached_or_compiled(const std::string& scan, Variant 
         if (!compile(scan, variant, *fresh, why)) return nullptr;
         if (compile_seconds) *compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::lock_guard<std::mutex> lock(g_cache_mutex);
-        code = g_cache.emplace(key, fresh).first->second;
+        const auto inserted = g_cache.emplace(key, fresh);
+        code = inserted.first->second;
+        if (inserted.second) {
+            g_cache_order.push_back(key);
+            while (g_cache_order.size() > kMaxCached) {
+                g_cache.erase(g_cache_order.front());
+                g_cache_order.pop_front();
+            }
+        }
     }
     return code;
 }
