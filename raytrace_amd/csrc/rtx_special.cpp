@@ -371,7 +371,10 @@ void finish(const std::shared_ptr<Job>& job) {
 }
 
 void unload(Kernel& k) {
-    if (k.module) (void)hipModuleUnload(k.module);
+    if (k.module) {
+        (void)hipDeviceSynchronize();  // (a launch of these kernels may still be in flight on a caller's stream)
+        (void)hipModuleUnload(k.module);
+    }
     k = Kernel{};
 }
 
