@@ -352,6 +352,32 @@ def test_scan_compiled_for_the_scene_agrees_with_the_table_scan(gpu_ctx, name, l
     del keep
 
 
+@pytest.mark.parametrize("w,h,spp", [(57, 35, 3), (1, 1, 33), (130, 2, 5), (5, 3, 7), (200, 113, 1)])
+def test_compiled_kernels_on_ragged_frames(gpu_ctx, w, h, spp):
+    """Tiles that hang over the frame's edge, a single pixel, odd sample counts: the kernels compiled for the scene
+    against the table-driven ones sample for sample, and each frame against the sum of its samples."""
+    scene = api.HostScene("cornell", w, h)
+    p = gpu_ctx.params(w, h, 1, spp, mode=api.RTX_MODE_FAST, seed=41)
+    out = {}
+    try:
+        for compiled in (0, 1):
+            gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, compiled)
+            gpu_ctx.upload(scene, api.RTX_ACCEL_LINEAR)
+            assert gpu_ctx.info().scan_specialized == compiled
+            rgb, seg = gpu_ctx.render_samples(p)
+            frame, rays = gpu_ctx.render(p)
+            assert int(seg.sum()) == rays and seg.min() >= 1
+            assert np.allclose(frame, rgb.reshape(h, w, spp, 3).sum(axis=2)[::-1], rtol=1e-4, atol=1e-5)
+            out[compiled] = (rgb, seg)
+    finally:
+        gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 1)
+    same = out[0][1] == out[1][1]
+    allowed = max(2, int(0.005 * same.size))
+    assert (~same).sum() <= allowed, ((~same).sum(), same.size)
+    close = np.isclose(out[0][0], out[1][0], rtol=2e-2, atol=1e-3).all(axis=-1)
+    assert (~(close | ~same)).sum() <= allowed
+
+
 def test_background_compilation_does_not_hold_up_the_upload_and_takes_over_when_ready(gpu_ctx):
     """RTX_OPTION_SPECIALIZE_SCAN = 2: the upload returns without waiting for the compiler, frames come from
     the table-driven kernels until the compiled ones are in the process's cache, and the next call takes
