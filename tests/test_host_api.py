@@ -108,6 +108,19 @@ def test_scene_features_and_lights_in_the_generated_source():
     assert f & fuzz and f & dielectric
 
 
+def test_kernel_source_into_a_short_buffer_is_cut_and_terminated():
+    lib = api.load_librtx()
+    scene = api.HostScene("cornell", 16, 9)
+    needed = ctypes.c_uint64(0)
+    assert lib.rtx_scene_kernel_source(scene.view_ptr, None, 0, ctypes.byref(needed)) == api.RTX_OK
+    whole = api.scene_kernel_source(scene)
+    assert needed.value == len(whole) + 1
+    buf = ctypes.create_string_buffer(b"\xff" * 64, 64)
+    assert lib.rtx_scene_kernel_source(scene.view_ptr, buf, 24, None) == api.RTX_OK
+    assert buf.raw[:23] == whole.encode()[:23] and buf.raw[23] == 0 and buf.raw[24] == 0xff
+    assert lib.rtx_scene_kernel_source(None, buf, 24, None) == api.RTX_ERR_INVALID_ARGUMENT
+
+
 def test_scenes_compile_concurrently_from_several_threads():
     """rtx_prepare_scene is what an application calls from worker threads: four scenes at once, then each
     again from the cache."""
