@@ -400,8 +400,8 @@ def test_background_compilation_does_not_hold_up_the_upload_and_takes_over_when_
         info = gpu_ctx.info()
         assert info.scan_specialized == 1 and gpu_ctx.note() == "", gpu_ctx.note()
         assert info.specialize_seconds > 0.05
-        assert upload_seconds < info.specialize_seconds + 0.15, (upload_seconds, info.specialize_seconds)
-        assert note in ("compiling in the background", "")
+        # (the upload came back while the compiler was still at work: that is what its note said)
+        assert note == "compiling in the background" and upload_seconds < 2.0, (note, upload_seconds)
         second, second_rays = gpu_ctx.render(p)
         # another context takes the code object from the cache at once, whatever its option says
         gpu_ctx.set_option(api.RTX_OPTION_SPECIALIZE_SCAN, 1)
