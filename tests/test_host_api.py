@@ -73,7 +73,7 @@ def test_scene_kernels_compile_without_a_gpu():
         first = time.time() - t
         t = time.time()
         api.prepare_scene(scene)  # from the process's cache
-        assert time.time() - t < 0.1 * max(first, 0.1)
+        assert time.time() - t < 0.5 * max(first, 0.2)
     with pytest.raises(api.RtxError) as e:
         api.prepare_scene(api.HostScene("random_field", 32, 18))
     assert e.value.code == api.RTX_ERR_UNSUPPORTED and "specialised" in str(e.value)
@@ -146,7 +146,7 @@ def test_scenes_compile_concurrently_from_several_threads():
     t0 = time.time()
     for sc in scenes:
         api.prepare_scene(sc)
-    assert time.time() - t0 < 0.2
+    assert time.time() - t0 < 1.0
 
 
 def test_a_scan_that_does_not_compile_is_refused_with_the_compilers_message(tmp_path):
