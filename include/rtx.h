@@ -211,16 +211,17 @@ int rtx_device_count(void);
  *       outputs and rtx_hit of a scene all come from the compiled scan.  An upload takes 0.2 - 0.7 s
  *       longer the first time a process sees the scene.  Where the run-time compiler is missing or
  *       fails the table-driven kernels render (rtx_scene_info and rtx_scene_note say so).  0: never.
- *       2: in the background - rtx_upload_scene starts the compilation on a thread of its own and
- *       returns at once; the table-driven kernels render until the compiled ones are ready, and
- *       the first render call (or rtx_scene_info) after that takes them over, which loads a code
- *       object on the device (rtx_render_noalloc never does: it goes on with what the context
- *       has; rtx_destroy and a new upload wait for a compilation that is still running, and so does
- *       the end of the process for contexts never destroyed).  Samples rendered before and after the
- *       switch come from two compilations of the same
- *       estimator and differ in rounding only; which call switches depends on timing, so choose 0
- *       or 1 where two runs must give the same bits.  When does it pay: the compilation costs about
- *       as much as 3 s of rendering gain back (x 1.07 - 1.22, more with dozens of lights).
+ *       2: in the background - rtx_upload_scene hands the compilation to a helper program (rtx_compile,
+ *       installed beside the library; a thread of the library waits for it) and returns at once; the
+ *       table-driven kernels render until the compiled ones are ready, and the first render call (or
+ *       rtx_scene_info) after that takes them over, which loads a code object on the device
+ *       (rtx_render_noalloc never does: it goes on with what the context has).  rtx_destroy and a new
+ *       upload end a compilation that is still running; a process may exit while one runs.  Samples
+ *       rendered before and after the switch come from two compilations of the same estimator and
+ *       differ in rounding only; which call switches depends on timing, so choose 0 or 1 where two runs
+ *       must give the same bits.  Without the helper program the table-driven kernels stay
+ *       (rtx_scene_note says so).  When does a compilation pay: it costs about as much as 3 s of
+ *       rendering gain back (x 1.07 - 1.22, more with dozens of lights).
  *       Deterministic mode is not affected.
  */
 enum { RTX_OPTION_SPECIALIZE_SCAN = 1 };

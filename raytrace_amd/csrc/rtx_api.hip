@@ -509,8 +509,8 @@ rtxspecial::Variant scan_variant(const RtxScene* s, bool light_tree) {
     return v;
 }
 
-// Takes over the kernels a background compilation has finished (called by the render entry points,
-// with the context's device current): from the process's cache onto this device.
+// Takes over the kernels a background compilation (the helper program's, see rtx_special.h) has finished -
+// called by the render entry points, with the context's device current: from the process's cache onto this device.
 void adopt_special_job(RtxContext* ctx) {
     if (!ctx->special_job) return;
     const int state = ctx->special_job->state.load(std::memory_order_acquire);
@@ -661,7 +661,7 @@ int rtx_create(int device, RtxContext** out_ctx) {
 void rtx_destroy(RtxContext* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    rtxspecial::finish(ctx->special_job);  // (waits for a compilation still running)
+    rtxspecial::finish(ctx->special_job);  // (ends a compilation still running)
     rtxspecial::unload(ctx->special);
     delete ctx;
 }
@@ -906,7 +906,7 @@ int rtx_upload_scene(RtxContext* ctx, const RtxScene* s, uint32_t accel) {
     // the scan of a small scene compiled into the fast-mode trace kernel (the variant launch_trace would pick
     // for this scene's frames)
     rtxspecial::unload(ctx->special);
-    rtxspecial::finish(ctx->special_job);  // (waits for a compilation still running for the scene replaced)
+    rtxspecial::finish(ctx->special_job);  // (ends a compilation still running for the scene replaced)
     ctx->special_job.reset();
     ctx->special_note.clear();
     ctx->info.scan_specialized = 0;

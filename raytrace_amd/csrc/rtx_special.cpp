@@ -3,6 +3,12 @@
 #include "rtx_special.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <spawn.h>
+#include <sys/socket.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdarg>
@@ -57,8 +63,8 @@ struct Rtc {
     std::string why;
 };
 
-// (this and the cache below are never destroyed: they must outlive every compiler thread, whatever the
-// order in which the process's static objects go)
+// (this and the cache below are never destroyed: threads of the application may still compile or load while
+// the process's static objects go)
 const Rtc& rtc() {
     static Rtc& r = *new Rtc;
     static std::once_flag once;
@@ -259,8 +265,25 @@ std::string scan_source(const std::vector<rtxd::ScanGroup>& groups, const std::v
 }
 
 namespace {
+std::string cache_key(const std::string& text, Variant variant) {
+    return std::string(variant.light_tree ? "T" : "t") + (variant.list_lit ? "L" : "l") + text;
+}
+
+std::shared_ptr<CodeObject> insert_code(const std::string& key, const std::shared_ptr<CodeObject>& fresh) {
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    const auto inserted = g_cache.emplace(key, fresh);
+    if (inserted.second) {
+        g_cache_order.push_back(key);
+        while (g_cache_order.size() > kMaxCached) {
+            g_cache.erase(g_cache_order.front());
+            g_cache_order.pop_front();
+        }
+    }
+    return inserted.first->second;
+}
+
 std::shared_ptr<CodeObject> cached_or_compiled(const std::string& scan, Variant variant, std::string& why, double* compile_seconds) {
-    const std::string key = std::string(variant.light_tree ? "T" : "t") + (variant.list_lit ? "L" : "l") + scan;
+    const std::string key = cache_key(scan, variant);
     if (compile_seconds) *compile_seconds = 0.0;
     std::shared_ptr<CodeObject> code;
     {
@@ -273,16 +296,7 @@ std::shared_ptr<CodeObject> cached_or_compiled(const std::string& scan, Variant 
         const auto t0 = std::chrono::steady_clock::now();
         if (!compile(scan, variant, *fresh, why)) return nullptr;
         if (compile_seconds) *compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        std::lock_guard<std::mutex> lock(g_cache_mutex);
-        const auto inserted = g_cache.emplace(key, fresh);
-        code = inserted.first->second;
-        if (inserted.second) {
-            g_cache_order.push_back(key);
-            while (g_cache_order.size() > kMaxCached) {
-                g_cache.erase(g_cache_order.front());
-                g_cache_order.pop_front();
-            }
-        }
+        code = insert_code(key, fresh);
     }
     return code;
 }
@@ -319,18 +333,119 @@ bool load(const std::string& scan, Variant variant, Kernel& out, std::string& wh
     return true;
 }
 
-namespace {
-std::mutex& g_jobs_mutex = *new std::mutex;
-std::vector<std::shared_ptr<Job>>& g_jobs = *new std::vector<std::shared_ptr<Job>>;  // started, not yet joined
-
-void join_all_jobs() {
-    std::vector<std::shared_ptr<Job>> jobs;
-    {
-        std::lock_guard<std::mutex> lock(g_jobs_mutex);
-        jobs.swap(g_jobs);
+// ---------------------------------------------------------------------------------------------
+// Compilations in the background run in a process of their own (the helper rtx_compile beside the
+// library): the thread below only feeds it and waits.  A compiler running on a thread of THIS process
+// would still be at work when a process that never destroyed its context exits, while the compiler's
+// own static objects are torn down under it (measured: an abort, a segmentation fault or a thread that
+// never ends); a helper is simply left behind and ends by itself.
+// Wire format: to the helper "<light_tree> <list_lit>\n" + the text; back "OK\n", then per kernel
+// "<lowered name>\n", then "<bytes>\n" and the code object - or "ERR\n" and the reason.
+// ---------------------------------------------------------------------------------------------
+bool compile_for_helper(const std::string& text, Variant variant, std::string& reply) {
+    CodeObject code;
+    std::string why;
+    if (!compile(text, variant, code, why)) {
+        reply = "ERR\n" + why;
+        return false;
     }
-    for (const std::shared_ptr<Job>& job : jobs)
-        if (job->thread.joinable()) job->thread.join();
+    reply = "OK\n";
+    for (int k = 0; k < kKernels; ++k) reply += code.kernel[k] + "\n";
+    reply += std::to_string(code.image.size()) + "\n";
+    reply.append(code.image.data(), code.image.size());
+    return true;
+}
+
+namespace {
+std::string helper_path() {
+    Dl_info info{};
+    if (!dladdr(reinterpret_cast<void*>(&compile_for_helper), &info) || !info.dli_fname) return std::string();
+    std::string path = info.dli_fname;
+    const size_t slash = path.rfind('/');
+    path = slash == std::string::npos ? std::string("rtx_compile") : path.substr(0, slash + 1) + "rtx_compile";
+    return access(path.c_str(), X_OK) == 0 ? path : std::string();
+}
+
+// Runs the helper on (text, variant); the code object lands in the cache.  False with the reason.
+bool compile_in_helper(Job& job, std::string& why) {
+    const std::string path = helper_path();
+    if (path.empty()) {
+        why = "the compile helper (rtx_compile beside librtx.so) is missing";
+        return false;
+    }
+    int to_child[2], from_child[2];  // a socket pair towards the helper (a write to a helper that died is an error, not a signal)
+    if (socketpair(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0, to_child) != 0) {
+        why = "socketpair failed";
+        return false;
+    }
+    if (pipe2(from_child, O_CLOEXEC) != 0) {
+        close(to_child[0]);
+        close(to_child[1]);
+        why = "pipe2 failed";
+        return false;
+    }
+    posix_spawn_file_actions_t actions;
+    posix_spawn_file_actions_init(&actions);
+    posix_spawn_file_actions_adddup2(&actions, to_child[0], 0);
+    posix_spawn_file_actions_adddup2(&actions, from_child[1], 1);
+    char* const argv[] = {const_cast<char*>(path.c_str()), nullptr};
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, path.c_str(), &actions, nullptr, argv, environ);
+    posix_spawn_file_actions_destroy(&actions);
+    close(to_child[0]);
+    close(from_child[1]);
+    if (rc != 0) {
+        close(to_child[1]);
+        close(from_child[0]);
+        why = std::string("cannot start ") + path + ": " + std::strerror(rc);
+        return false;
+    }
+    job.helper_pid.store((int)pid, std::memory_order_release);
+    const std::string request = std::string(job.variant.light_tree ? "1 " : "0 ") + (job.variant.list_lit ? "1\n" : "0\n") + job.text;
+    size_t sent = 0;
+    while (sent < request.size()) {
+        const ssize_t n = send(to_child[1], request.data() + sent, request.size() - sent, MSG_NOSIGNAL);
+        if (n <= 0) break;
+        sent += (size_t)n;
+    }
+    shutdown(to_child[1], SHUT_WR);
+    std::string reply;
+    char buf[65536];
+    for (;;) {
+        const ssize_t n = read(from_child[0], buf, sizeof buf);
+        if (n <= 0) break;
+        reply.append(buf, (size_t)n);
+    }
+    close(to_child[1]);
+    close(from_child[0]);
+    int status = 0;
+    (void)waitpid(pid, &status, 0);
+    job.helper_pid.store(0, std::memory_order_release);
+    if (reply.compare(0, 3, "OK\n") != 0) {
+        why = reply.compare(0, 4, "ERR\n") == 0 ? reply.substr(4, 600) : std::string("the compile helper ended without an answer");
+        return false;
+    }
+    auto code = std::make_shared<CodeObject>();
+    size_t at = 3;
+    auto line = [&](std::string& out) {
+        const size_t end = reply.find('\n', at);
+        if (end == std::string::npos) return false;
+        out = reply.substr(at, end - at);
+        at = end + 1;
+        return true;
+    };
+    std::string size_text;
+    bool ok = true;
+    for (int k = 0; k < kKernels; ++k) ok = ok && line(code->kernel[k]);
+    ok = ok && line(size_text);
+    const size_t size = ok ? (size_t)std::strtoull(size_text.c_str(), nullptr, 10) : 0;
+    if (!ok || size == 0 || reply.size() - at != size) {
+        why = "the compile helper's answer is malformed";
+        return false;
+    }
+    code->image.assign(reply.begin() + (long)at, reply.end());
+    insert_code(cache_key(job.text, job.variant), code);
+    return true;
 }
 }  // namespace
 
@@ -338,36 +453,32 @@ std::shared_ptr<Job> start(const std::string& text, Variant variant) {
     auto job = std::make_shared<Job>();
     job->text = text;
     job->variant = variant;
-    // The compiler library is loaded before the exit handler is registered: handlers run in reverse
-    // order, so the threads are joined before that library's own objects go.
-    (void)rtc();
-    static std::once_flag registered;
-    std::call_once(registered, [] { std::atexit(join_all_jobs); });
     {
-        std::lock_guard<std::mutex> lock(g_jobs_mutex);
-        g_jobs.push_back(job);
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        if (g_cache.count(cache_key(text, variant))) {  // (already compiled in this process: nothing to start)
+            job->state.store(1, std::memory_order_release);
+            return job;
+        }
     }
-    Job* raw = job.get();  // (kept alive by g_jobs until the thread has been joined)
-    job->thread = std::thread([raw] {
+    std::shared_ptr<Job> keep = job;  // (the thread holds the job: its owner may drop it at any time)
+    job->thread = std::thread([keep] {
+        const auto t0 = std::chrono::steady_clock::now();
         std::string why;
-        const bool ok = prepare(raw->text, raw->variant, why, &raw->seconds);
-        raw->why = why;
-        raw->state.store(ok ? 1 : 2, std::memory_order_release);
+        const bool ok = compile_in_helper(*keep, why);
+        keep->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        keep->why = why;
+        keep->state.store(ok ? 1 : 2, std::memory_order_release);
     });
     return job;
 }
 
 void finish(const std::shared_ptr<Job>& job) {
-    if (!job) return;
-    {
-        std::lock_guard<std::mutex> lock(g_jobs_mutex);
-        for (size_t k = 0; k < g_jobs.size(); ++k)
-            if (g_jobs[k] == job) {
-                g_jobs.erase(g_jobs.begin() + (long)k);
-                break;
-            }
+    if (!job || !job->thread.joinable()) return;
+    if (job->state.load(std::memory_order_acquire) == 0) {  // still compiling: its owner has no use for the result
+        const int pid = job->helper_pid.load(std::memory_order_acquire);
+        if (pid > 0) (void)kill((pid_t)pid, SIGTERM);
     }
-    if (job->thread.joinable()) job->thread.join();
+    job->thread.join();
 }
 
 void unload(Kernel& k) {

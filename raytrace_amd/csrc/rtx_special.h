@@ -68,21 +68,31 @@ bool prepare(const std::string& text, Variant variant, std::string& why, double*
 
 void unload(Kernel& k);
 
-// A compilation on a thread of its own (RTX_OPTION_SPECIALIZE_SCAN = 2).  The thread only compiles
-// into the process's cache (no device call); the owner polls `state` and, once it is not 0, loads
-// the code object with load().  The thread is joined by finish() - which the owner calls before it
-// drops the job, so a context that is destroyed or gets another scene waits for its compilation -
-// and, for jobs whose owner never did, when the process exits: a compiler thread still running
-// while the process's libraries are torn down corrupts the heap.
+// A compilation in the background (RTX_OPTION_SPECIALIZE_SCAN = 2): a thread of the library runs the
+// helper program rtx_compile (beside librtx.so) on the text, waits for it and puts the code object
+// into the process's cache; the owner polls `state` and, once it is not 0, loads the code object with
+// load().  The compiler itself never runs on a background thread of this process: a process may
+// exit at any time, and a compiler caught by the teardown of its own static objects aborts, faults or
+// hangs - a helper that is left behind just ends.  finish() ends a compilation nobody waits for any
+// more (the helper is terminated) and joins the thread; a job whose owner never calls it is harmless.
 struct Job {
     std::string text;
     Variant variant;
     std::atomic<int> state{0};  // 0 compiling, 1 in the cache, 2 failed
     std::string why;            // (written before state becomes 2)
     double seconds = 0.0;
+    std::atomic<int> helper_pid{0};
     std::thread thread;
+    // (the thread shares the job with its owner: whoever drops it last - the thread itself, if the owner never
+    // called finish() - must not destroy a thread that can still be joined)
+    ~Job() {
+        if (thread.joinable()) thread.detach();
+    }
 };
 std::shared_ptr<Job> start(const std::string& text, Variant variant);
 void finish(const std::shared_ptr<Job>& job);
+
+// The helper's side: compiles and writes the answer of the wire format (rtx_special.cpp) into `reply`.
+bool compile_for_helper(const std::string& text, Variant variant, std::string& reply);
 
 }  // namespace rtxspecial

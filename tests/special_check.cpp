@@ -3,13 +3,15 @@
 // crash, because rtx_upload_scene then keeps the table-driven kernels and reports the reason.  The
 // generators: feature set, scan and light list of a hand-made table, whose text must compile.
 // Built by tests/test_host_api.py with hipcc against raytrace_amd/csrc/rtx_special.cpp + rtx_sources.cpp.
+#include <chrono>
 #include <cstdio>
+#include <thread>
 #include <string>
 #include <vector>
 
 #include "rtx_special.h"
 
-int main() {
+int main(int argc, char** argv) {
     std::string why;
     double seconds = -1.0;
     const std::string bad = "#define RTX_SPECIAL_SCAN this is not C++;\n";
@@ -80,6 +82,51 @@ int main() {
     if (why.find("not available") == std::string::npos && !rtxspecial::prepare(text, list_lit, gen_why, nullptr)) {
         std::printf("FAIL: the generated text did not compile: %s\n", gen_why.c_str());
         return 1;
+    }
+    // compilations in the background (the helper rtx_compile must lie beside this program): one that succeeds,
+    // one that fails with the compiler's message, one whose owner gives up at once
+    if (argc > 1 && std::string(argv[1]) == "--jobs" && why.find("not available") == std::string::npos) {
+        auto wait_for = [](const std::shared_ptr<rtxspecial::Job>& job) {
+            for (int k = 0; k < 3000 && job->state.load() == 0; ++k) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            return job->state.load();
+        };
+        const std::string fresh = good + "// a text this process has not compiled yet\n";
+        auto ok_job = rtxspecial::start(fresh, rtxspecial::Variant{});
+        auto bad_job = rtxspecial::start(bad + "// again\n", rtxspecial::Variant{});
+        if (wait_for(ok_job) != 1) {
+            std::printf("FAIL: background job: state %d, %s\n", ok_job->state.load(), ok_job->why.c_str());
+            return 1;
+        }
+        if (wait_for(bad_job) != 2 || bad_job->why.find("run-time compilation failed") == std::string::npos) {
+            std::printf("FAIL: a failing background job reports state %d, '%s'\n", bad_job->state.load(), bad_job->why.c_str());
+            return 1;
+        }
+        rtxspecial::finish(ok_job);
+        rtxspecial::finish(bad_job);
+        std::string cached_why;
+        double seconds = -1.0;
+        if (!rtxspecial::prepare(fresh, rtxspecial::Variant{}, cached_why, &seconds) || seconds != 0.0) {
+            std::printf("FAIL: the helper's code object is not in the cache\n");
+            return 1;
+        }
+        auto again = rtxspecial::start(fresh, rtxspecial::Variant{});  // already in the cache: done at once, no thread
+        if (again->state.load() != 1 || again->thread.joinable()) {
+            std::printf("FAIL: a cached text started a compilation\n");
+            return 1;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        auto dropped = rtxspecial::start(good + "// given up\n", rtxspecial::Variant{});
+        std::this_thread::sleep_for(std::chrono::milliseconds(30));
+        rtxspecial::finish(dropped);  // ends the helper instead of waiting for it
+        const double gave_up = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (gave_up > 5.0) {
+            std::printf("FAIL: finish() waited %.1f s\n", gave_up);
+            return 1;
+        }
+        auto left = rtxspecial::start(good + "// never finished by its owner\n", rtxspecial::Variant{});
+        (void)left;  // the process ends with this one still compiling
+        std::printf("OK jobs\n");
+        return 0;
     }
     std::printf("OK reason: %.120s\n", why.c_str());
     return 0;

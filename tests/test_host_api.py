@@ -164,6 +164,33 @@ def test_a_scan_that_does_not_compile_is_refused_with_the_compilers_message(tmp_
                     sources, "-ldl", "-o", exe], check=True, capture_output=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+    # compilations in the background run in the helper program beside the library (here: beside the test program);
+    # the last job of the run is still compiling when the process ends, which must be a clean exit
+    import shutil
+
+    helper = os.path.join(ROOT, "raytrace_amd", "rtx_compile")
+    assert os.path.exists(helper), "raytrace_amd/rtx_compile is not built (make -C raytrace_amd/csrc)"
+    shutil.copy(helper, str(tmp_path / "rtx_compile"))
+    out = subprocess.run([exe, "--jobs"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK jobs"), out.stdout + out.stderr
+
+
+def test_the_compile_helper_answers_in_the_wire_format():
+    """raytrace_amd/rtx_compile by itself: a scene's text in, lowered kernel names and a code object out;
+    a malformed request and a text that does not compile come back as errors."""
+    import subprocess
+
+    helper = os.path.join(ROOT, "raytrace_amd", "rtx_compile")
+    text = api.scene_kernel_source(api.HostScene("cornell_classic", 16, 9))
+    out = subprocess.run([helper], input=b"0 1\n" + text.encode(), capture_output=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith(b"OK\n")
+    lines = out.stdout.split(b"\n", 5)
+    assert b"trace_kernel" in lines[1] and b"trace_kernel" in lines[2] and b"hit_kernel" in lines[3]
+    assert int(lines[4]) == len(lines[5]) and lines[5][:4] == b"\x7fELF"
+    out = subprocess.run([helper], input=b"nonsense", capture_output=True, timeout=60)
+    assert out.stdout.startswith(b"ERR\n")
+    out = subprocess.run([helper], input=b"0 0\n#define RTX_SPECIAL_SCAN this is not C++;\n", capture_output=True, timeout=300)
+    assert out.returncode == 1 and out.stdout.startswith(b"ERR\n") and b"run-time compilation failed" in out.stdout
 
 
 def test_generated_scan_lists_every_primitive_of_the_scene_once():
