@@ -234,7 +234,7 @@ int rtx_set_option(RtxContext* ctx, uint32_t option, uint64_t value);
  * code object is in the cache afterwards; RTX_ERR_UNSUPPORTED when the scene is not one whose scan
  * is specialised or the run-time compiler is missing or failed (rtx_last_error says which).
  * A thread that is inside this call must be joined before the process exits: the run-time compiler
- * does not survive the teardown of its own static objects (option value 2 below has no such
+ * does not survive the teardown of its own static objects (value 2 of RTX_OPTION_SPECIALIZE_SCAN has no such
  * condition, it compiles in a helper process).
  */
 int rtx_prepare_scene(const RtxScene* scene);
